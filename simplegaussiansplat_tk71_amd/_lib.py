@@ -1,0 +1,71 @@
+"""ctypes binding of libgrouped_cumprod_hip.so (the C ABI of include/grouped_cumprod_hip.h).
+
+There is NO fallback: if the library is missing or does not load, importing the
+ops raises.  The reference has the same property — `import grouped_cumprod`
+fails when its extension is not built (reference: gs_model.py:8).
+"""
+import ctypes
+import os
+
+from ._build import LIB_PATH
+
+_c_void_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/grouped_cumprod_hip.h declares
+SIGNATURES = {
+    "gcp_abi_version": (ctypes.c_int, []),
+    "gcp_last_hip_error": (ctypes.c_int, []),
+    "gcp_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "gcp_workspace_bytes": (_sz, [_i64]),
+    "gcp_workspace_init": (ctypes.c_int, [_c_void_p, _sz, _c_void_p]),
+    "gcp_cumprod_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_reverse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumprod_backward": (
+        ctypes.c_int,
+        [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _c_void_p, _sz, _c_void_p],
+    ),
+    "gcp_check_groups": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, ctypes.POINTER(_i64), _c_void_p]),
+    "gcp_tile_elems": (ctypes.c_int, []),
+    "gcp_last_fallback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
+}
+
+ABI_VERSION = 1
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("GCP_LIBRARY", LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python setup.py build_ext --inplace` "
+            "(or __graft_entry__.build()). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.gcp_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    """Turn a GCP_* status into the RuntimeError the reference's callers would see."""
+    if status == 0:
+        return
+    lib = load()
+    msg = lib.gcp_status_string(status).decode()
+    if status == 3:
+        msg += f" (hipError {lib.gcp_last_hip_error()})"
+    raise RuntimeError(f"{what}: {msg}")

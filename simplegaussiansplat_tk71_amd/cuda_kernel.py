@@ -1,0 +1,160 @@
+"""Autograd layer and the scan call sites of the reference, on the HIP library.
+
+The reference's `cuda_kernel.py` (reference: cuda_kernel.py:1-19) is a stale JIT
+loader; its autograd code lives in gs_model.py.  This module is what
+BASELINE.json's north_star asks `cuda_kernel.py` to be: real
+`torch.autograd.Function`s over the grouped scans, plus the two helpers of
+`custom_autograd_grouped_cumprod` that are the only in-repo callers of the
+extension:
+
+  create_alpha_brend  <- gs_model.py:544-566 (_create_alpha_brend)
+  grad_cumsum         <- gs_model.py:716-722
+  unique              <- gs_model.py:538-541 (pixel key = y*10000 + x, int32)
+
+Deliberate differences from the reference, all result-preserving:
+  * `torch.sort(..., stable=True)`: depth order inside a pixel is carried only by
+    sort stability; the reference calls torch.sort without it (gs_model.py:547),
+    which is stable on CUDA in practice and NOT on CPU for small inputs.
+  * the un-sort `output[torch.argsort(index)]` (gs_model.py:555, a second radix
+    sort) is done as the equivalent scatter `unsorted[index] = output`.
+  * grad_cumsum's flip / scan / flip is one reverse scan on the same sorted keys.
+"""
+import torch
+
+from . import grouped_cumprod as _ext
+
+__all__ = [
+    "GroupedCumprod",
+    "GroupedCumsum",
+    "grouped_cumprod",
+    "grouped_cumsum",
+    "unique",
+    "create_alpha_brend",
+    "create_alpha_blend",
+    "grad_cumsum",
+]
+
+
+class GroupedCumprod(torch.autograd.Function):
+    """y = inclusive product scan of x inside runs of equal adjacent `key` (int32).
+
+    backward = grouped_cumprod_backward (reference kernel semantics,
+    cuda_kernel/grouped_cumprod_backward.cu:22-29, incl. the 0 -> 1e-8 divisor).
+    """
+
+    @staticmethod
+    def forward(ctx, x, key):
+        y = torch.empty_like(x)
+        _ext.grouped_cumprod_forward(x, key, y)
+        ctx.save_for_backward(x, y, key)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, y, key = ctx.saved_tensors
+        grad_x = torch.empty_like(x)
+        # The kernel reads group ends from the runs of `inv`; the key array itself has
+        # the same runs, and inv_len is only part of the reference signature.
+        inv_len = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _ext.grouped_cumprod_backward(x, y, grad_y.contiguous(), key, grad_x, inv_len)
+        return grad_x, None
+
+
+class GroupedCumsum(torch.autograd.Function):
+    """y = inclusive sum scan inside runs of equal adjacent `key`; backward = suffix sums."""
+
+    @staticmethod
+    def forward(ctx, x, key):
+        y = torch.empty_like(x)
+        _ext.grouped_cumsum_forward(x, key, y)
+        ctx.save_for_backward(key)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (key,) = ctx.saved_tensors
+        grad_x = torch.empty_like(grad_y)
+        _ext.grouped_cumsum_reverse(grad_y.contiguous(), key, grad_x)
+        return grad_x, None
+
+
+def grouped_cumprod(x, key):
+    return GroupedCumprod.apply(x, key)
+
+
+def grouped_cumsum(x, key):
+    return GroupedCumsum.apply(x, key)
+
+
+def unique(rects):
+    """Pixel key of every pair: y*10000 + x in int32 (reference: gs_model.py:538-541)."""
+    with torch.no_grad():
+        rects = rects.to(torch.int32)
+        return rects[:, 1] * 10000 + rects[:, 0]
+
+
+def _mask_zero_T(T):
+    # reference: gs_model.py:575-578
+    mask = T != 0
+    return [T[mask], mask]
+
+
+def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None):
+    """Per-pixel exclusive transmittance (flag="cumprod") or exclusive prefix sum
+    (flag="cumsum") of `anti_opacity`, returned in the ORIGINAL pair order.
+
+    reference: gs_model.py:544-566.  Steps kept one for one: key, stable sort, gather,
+    grouped scan, un-sort, drop `cutting_number` carry rows, compact the entries whose
+    inclusive value is exactly 0 (:560, :575-578), then inclusive / self (:562) or
+    inclusive - self (:564).  Returns [values, mask].
+    """
+    with torch.no_grad():
+        inv = unique(rects)
+        sorted_inv, index = torch.sort(inv, stable=True)
+        sorted_anti_opacity = anti_opacity[index]
+        output = torch.zeros_like(sorted_anti_opacity)
+        if flag == "cumprod":
+            _ext.grouped_cumprod_forward(sorted_anti_opacity, sorted_inv.to(torch.int32), output)
+        elif flag == "cumsum":
+            _ext.grouped_cumsum_forward(sorted_anti_opacity, sorted_inv.to(torch.int32), output)
+        unsorted = torch.empty_like(output)
+        unsorted[index] = output  # == output[torch.argsort(index)]
+        output = unsorted
+        if cutting_number:
+            output = output[cutting_number:]
+            anti_opacity = anti_opacity[cutting_number:]
+        output, mask = _mask_zero_T(output)
+        if flag == "cumprod":
+            output = output / anti_opacity[mask]
+        elif flag == "cumsum":
+            output = output - anti_opacity[mask]
+        return [output, mask]
+
+
+create_alpha_blend = create_alpha_brend  # spelling alias
+
+
+def grad_cumsum(rects, grad, cutting_number=None):
+    """Per-pixel exclusive SUFFIX sum of `grad` in original pair order.
+
+    reference: gs_model.py:716-722 (flip, _create_alpha_brend(flag="cumsum"), flip).
+    Flipping a stably sorted list and summing forward equals summing backward on the
+    un-flipped list, so this runs one reverse scan instead.  `cutting_number` counts
+    rows at the START of the flipped arrays, i.e. the LAST rows of the inputs
+    (gs_model.py:636 appends the carry rows at the end before the flip).
+    """
+    with torch.no_grad():
+        inv = unique(rects)
+        sorted_inv, index = torch.sort(inv, stable=True)
+        sorted_grad = grad[index]
+        output = torch.zeros_like(sorted_grad)
+        _ext.grouped_cumsum_reverse(sorted_grad, sorted_inv.to(torch.int32), output)
+        unsorted = torch.empty_like(output)
+        unsorted[index] = output
+        output = unsorted
+        if cutting_number:
+            output = output[: output.numel() - cutting_number]
+            grad = grad[: grad.numel() - cutting_number]
+        mask = output != 0
+        output = output[mask] - grad[mask]
+        return [output, mask]

@@ -1,0 +1,166 @@
+"""Drop-in for the reference's compiled module `grouped_cumprod`.
+
+Same three functions, same positional arguments, same in-place-output convention
+(reference: cuda_kernel/cuda_kernel.cpp:5-22; callers gs_model.py:551,553 and
+cuda_test.py:23,29).  Each call is one asynchronous launch of the HIP library on
+the CURRENT PyTorch stream (the reference uses the legacy default stream,
+grouped_cumprod_backward.cu:56, and Thrust's blocking default policy).
+
+Contract (reference: data_ptr<float>()/data_ptr<int>() in
+grouped_cumprod_forward.cu:8-10 raise c10::Error -> RuntimeError on a dtype
+mismatch; nothing else is checked there).  Here every violation raises
+RuntimeError before anything is launched:
+  values float32, keys / ids / offsets int32, all on the same ROCm device,
+  contiguous, equal element counts.
+There is no CPU path: CPU tensors raise.  The CPU statement of these ops lives in
+oracle/ and is test infrastructure only.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "grouped_cumprod_forward",
+    "grouped_cumsum_forward",
+    "grouped_cumprod_backward",
+    "grouped_cumsum_reverse",
+    "check_groups",
+    "last_fallback_tiles",
+    "tile_elems",
+]
+
+_workspaces = {}  # (device index, stream handle) -> uint8 tensor
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_tensor(t, name, dtype, device, numel=None):
+    _require(isinstance(t, torch.Tensor), f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    want = "Float" if dtype is torch.float32 else "Int"
+    _require(t.dtype is dtype, f"{name}: expected scalar type {want} but found {t.dtype}")
+    _require(t.is_cuda, f"{name}: expected a ROCm device tensor, got device {t.device} (no CPU path)")
+    _require(t.device == device, f"{name}: on {t.device}, expected {device}")
+    _require(t.is_contiguous(), f"{name}: must be contiguous")
+    if numel is not None:
+        _require(t.numel() == numel, f"{name}: {t.numel()} elements, expected {numel}")
+
+
+def _workspace(device, stream_handle, n):
+    lib = _lib.load()
+    need = lib.gcp_workspace_bytes(n)
+    key = (device.index, stream_handle)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        # torch.zeros: the control words must start at zero (gcp_workspace_init contract)
+        ws = torch.zeros(max(need + need // 2, 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n=()):
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ws = _workspace(device, stream, n)
+        fn = getattr(lib, fn_name)
+        status = fn(*ptrs_before_n, n, *ptrs_after_n, ws.data_ptr(), ws.numel(), stream)
+    _lib.check(status, fn_name)
+
+
+def _forward(fn_name, x, key, y):
+    _require(isinstance(key, torch.Tensor), "pixel_index: expected a torch.Tensor")
+    n = key.numel()  # reference: n = pixel_index.numel() (grouped_cumprod_forward.cu:13)
+    dev = key.device
+    _check_tensor(key, "pixel_index", torch.int32, dev)
+    _check_tensor(x, "unti_opacity", torch.float32, dev, n)
+    _check_tensor(y, "out", torch.float32, dev, n)
+    if n == 0:
+        return
+    _launch(fn_name, dev, n, (x.data_ptr(), key.data_ptr(), y.data_ptr()))
+
+
+def grouped_cumprod_forward(unti_opacity, pixel_index, out):
+    """out[i] = prod of unti_opacity over the run of equal adjacent pixel_index up to i.
+
+    reference: cuda_kernel/grouped_cumprod_forward.cu:6-24.
+    """
+    _forward("gcp_cumprod_forward", unti_opacity, pixel_index, out)
+
+
+def grouped_cumsum_forward(unti_opacity, pixel_index, out):
+    """Same with a running sum.  reference: cuda_kernel/grouped_cumsum_forward.cu:6-24."""
+    _forward("gcp_cumsum_forward", unti_opacity, pixel_index, out)
+
+
+def grouped_cumsum_reverse(x, key, out):
+    """Suffix sums inside each run: flip -> grouped_cumsum_forward -> flip of the
+    reference (gs_model.py:716-722) in one pass.  Not in the reference module."""
+    _forward("gcp_cumsum_reverse", x, key, out)
+
+
+def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_len):
+    """grad_in[j] = sum_{i=j}^{inv_len[inv[j]]-1} grad_out[i] * param_cumprod[i] / p'_j.
+
+    reference: cuda_kernel/grouped_cumprod_backward.cu:9-65 (p'_j = param[j] or 1e-8
+    when it is 0, :25).  `inv` = dense group id per element, `inv_len` = exclusive
+    end offset per group (cuda_test.py:27).
+    """
+    _require(isinstance(param, torch.Tensor), "param: expected a torch.Tensor")
+    n = param.numel()  # reference: n = param.numel() (grouped_cumprod_backward.cu:52)
+    dev = param.device
+    _check_tensor(param, "param", torch.float32, dev)
+    _check_tensor(param_cumprod, "param_cumprod", torch.float32, dev, n)
+    _check_tensor(grad_out, "grad_out", torch.float32, dev, n)
+    _check_tensor(inv, "inv", torch.int32, dev, n)
+    _check_tensor(grad_in, "grad_in", torch.float32, dev, n)
+    _check_tensor(inv_len, "inv_len", torch.int32, dev)
+    if n == 0:
+        return
+    _require(inv_len.numel() > 0, "inv_len: empty for a non-empty input")
+    _launch(
+        "gcp_cumprod_backward",
+        dev,
+        n,
+        (param.data_ptr(), param_cumprod.data_ptr(), grad_out.data_ptr(), inv.data_ptr(), grad_in.data_ptr(),
+         inv_len.data_ptr()),
+        (inv_len.numel(),),
+    )
+
+
+def check_groups(inv, inv_len):
+    """Number of places where (inv, inv_len) is not a consistent dense partition (debug aid, synchronises)."""
+    dev = inv.device
+    n = inv.numel()
+    _check_tensor(inv, "inv", torch.int32, dev)
+    _check_tensor(inv_len, "inv_len", torch.int32, dev)
+    lib = _lib.load()
+    bad = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        status = lib.gcp_check_groups(inv.data_ptr(), inv_len.data_ptr(), n, inv_len.numel(), ctypes.byref(bad), stream)
+    _lib.check(status, "gcp_check_groups")
+    return bad.value
+
+
+def last_fallback_tiles(device=None):
+    """Tiles the most recent scan on the current stream fixed up through the descriptor fallback (synchronises)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    lib = _lib.load()
+    out = ctypes.c_int64(0)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ws = _workspaces.get((device.index, stream))
+        if ws is None:
+            return 0
+        status = lib.gcp_last_fallback_tiles(ws.data_ptr(), stream, ctypes.byref(out))
+    _lib.check(status, "gcp_last_fallback_tiles")
+    return out.value
+
+
+def tile_elems():
+    return _lib.load().gcp_tile_elems()

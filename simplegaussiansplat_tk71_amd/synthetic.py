@@ -1,0 +1,94 @@
+"""Synthetic depth-sorted splat-pixel pair lists.
+
+The scan never sees Gaussians, only the flat pair arrays the reference builds in
+`_create_alpha_brend` after its sort (reference: gs_model.py:546-548):
+  key      int32[M]  y*10000 + x (gs_model.py:538-541), sorted row-major, one run per pixel
+  x        f32[M]    1 - alpha * G  ("anti opacity", gs_model.py:533-535)
+  inv      int32[M]  dense group id 0..G-1          (cuda_test.py:21)
+  inv_len  int32[G]  exclusive end offset per group (cuda_test.py:27)
+  grad_out f32[M]    N(0,1)
+
+Named workloads = BASELINE.json `configs`:
+  cfg1  256x256,    D=8,   Poisson           (CPU plumbing case)
+  cfg2  1920x1080,  D=8,   Poisson           (100k Gaussians)
+  cfg3  1920x1080,  D=80,  deep heavy tail   (1M Gaussians)   <- the metric's configuration
+  cfg5  3840x2160,  D=100, deep heavy tail   (5M Gaussians, 8 GPUs)
+"""
+from dataclasses import dataclass
+
+import torch
+
+CONFIGS = {
+    "cfg1": dict(height=256, width=256, mean_depth=8.0, deep=False, gaussians=2_000),
+    "cfg2": dict(height=1080, width=1920, mean_depth=8.0, deep=False, gaussians=100_000),
+    "cfg3": dict(height=1080, width=1920, mean_depth=80.0, deep=True, gaussians=1_000_000),
+    "cfg5": dict(height=2160, width=3840, mean_depth=100.0, deep=True, gaussians=5_000_000),
+}
+
+MAX_RUN = 4096
+
+
+@dataclass
+class PairList:
+    key: torch.Tensor
+    x: torch.Tensor
+    inv: torch.Tensor
+    inv_len: torch.Tensor
+    grad_out: torch.Tensor
+    run_len: torch.Tensor  # int64[P] splats per pixel (zeros allowed)
+    height: int
+    width: int
+
+    @property
+    def n_pairs(self):
+        return self.key.numel()
+
+    @property
+    def n_groups(self):
+        return self.inv_len.numel()
+
+
+def run_lengths(n_pixels, mean_depth, deep, generator, device):
+    """Splats per pixel.  Poisson(D), or for "deep per-pixel lists" the mix
+    0.9*Poisson(D/2) + 0.1*Geometric(mean 5.5*D) (same mean D), clipped at 4096."""
+    if not deep:
+        lam = torch.full((n_pixels,), float(mean_depth), device=device)
+        return torch.poisson(lam, generator=generator).long().clamp_(max=MAX_RUN)
+    lam = torch.full((n_pixels,), float(mean_depth) / 2.0, device=device)
+    body = torch.poisson(lam, generator=generator)
+    u = torch.rand(n_pixels, device=device, generator=generator)
+    p = 1.0 / (5.5 * float(mean_depth))
+    v = torch.rand(n_pixels, device=device, generator=generator).clamp_(min=1e-12)
+    tail = torch.floor(torch.log(v) / torch.log1p(torch.tensor(-p, device=device))) + 1.0
+    return torch.where(u < 0.1, tail, body).long().clamp_(min=0, max=MAX_RUN)
+
+
+def make_pairs(height, width, mean_depth, deep=False, seed=0, device="cpu", row_start=0, gaussians=None):
+    """Pair list of an image band of `height` rows starting at image row `row_start`."""
+    del gaussians  # enters only through mean_depth
+    device = torch.device(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    n_pixels = height * width
+    L = run_lengths(n_pixels, mean_depth, deep, g, device)
+    ys = torch.arange(row_start, row_start + height, device=device, dtype=torch.int32)
+    xs = torch.arange(width, device=device, dtype=torch.int32)
+    pixel_key = (ys[:, None] * 10000 + xs[None, :]).reshape(-1)
+    key = torch.repeat_interleave(pixel_key, L)
+    m = key.numel()
+    nz = L > 0
+    inv_len = torch.cumsum(L[nz], 0).to(torch.int32)
+    inv = torch.repeat_interleave(torch.arange(int(nz.sum()), device=device, dtype=torch.int32), L[nz])
+    # opacity ~ sigmoid(N(1.7, 2.0)) clipped to [0.005, 0.995]: quantiles of the reference's opacity.pt
+    a = torch.sigmoid(torch.randn(m, device=device, generator=g) * 2.0 + 1.7).clamp_(0.005, 0.995)
+    gk = torch.rand(m, device=device, generator=g)
+    x = 1.0 - a * gk
+    grad_out = torch.randn(m, device=device, generator=g)
+    return PairList(key, x, inv, inv_len, grad_out, L, height, width)
+
+
+def make_config(name, seed=0, device="cpu", rows=None, row_start=0):
+    """One of BASELINE.json's configs; `rows` restricts it to an image band."""
+    c = CONFIGS[name]
+    h = c["height"] if rows is None else rows
+    return make_pairs(h, c["width"], c["mean_depth"], c["deep"], seed, device, row_start)

@@ -1,0 +1,161 @@
+"""Parity of the HIP scans (through the C ABI, via the drop-in module) against the CPU oracle.
+
+Tolerance: 1e-5 (BASELINE.json north_star), applied as 1e-5*(1+scale), see tests/util.py.
+"""
+import pytest
+import torch
+
+from tests.util import DISTRIBUTIONS, assert_parity, make_keys, make_values
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 12289, 100003]
+
+
+def _mods():
+    import grouped_cumprod as gc
+    from oracle import c_oracle as co
+
+    return gc, co
+
+
+def test_kat_cuda_test_py(device):
+    """reference: cuda_test.py:19-34 (expected backward printed at :34)."""
+    gc, _ = _mods()
+    param = torch.tensor([0.4, 0.2, 0.1, 0.8, 0.2], device=device)
+    grad = param.clone()
+    index = torch.tensor([0, 0, 1, 1, 2], device=device, dtype=torch.int32)
+    cp = torch.zeros_like(param)
+    gc.grouped_cumprod_forward(param, index, cp)
+    torch.testing.assert_close(cp.cpu(), torch.tensor([0.4, 0.08, 0.1, 0.08, 0.2]), atol=1e-7, rtol=1e-6)
+    out = torch.zeros_like(param)
+    index_len = torch.tensor([2, 4, 5], device=device, dtype=torch.int32)
+    gc.grouped_cumprod_backward(param, cp, grad, index, out, index_len)
+    torch.testing.assert_close(out.cpu(), torch.tensor([0.44, 0.08, 0.74, 0.08, 0.2]), atol=1e-6, rtol=1e-6)
+    cs = torch.zeros_like(param)
+    gc.grouped_cumsum_forward(param, index, cs)
+    torch.testing.assert_close(cs.cpu(), torch.tensor([0.4, 0.6, 0.1, 0.9, 0.2]), atol=1e-7, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dist", DISTRIBUTIONS)
+@pytest.mark.parametrize("n", SIZES)
+def test_forward_scans(device, n, dist):
+    gc, co = _mods()
+    key = make_keys(n, dist, seed=n)
+    x = make_values(n, seed=n, kind="alpha")
+    kd, xd = key.to(device), x.to(device)
+    y = torch.full_like(xd, float("nan"))
+    gc.grouped_cumprod_forward(xd, kd, y)
+    want = co.cumprod_forward(x, key)
+    assert_parity(y, want, co.cumprod_forward_f64(x, key), f"cumprod n={n} {dist}")
+
+    xs = make_values(n, seed=n + 5, kind="normal")
+    xsd = xs.to(device)
+    y = torch.full_like(xsd, float("nan"))
+    gc.grouped_cumsum_forward(xsd, kd, y)
+    assert_parity(y, co.cumsum_forward(xs, key), co.cumsum_forward_f64(xs.abs(), key), f"cumsum n={n} {dist}")
+
+    y = torch.full_like(xsd, float("nan"))
+    gc.grouped_cumsum_reverse(xsd, kd, y)
+    scale = co.cumsum_forward_f64(xs.abs().flip(0).contiguous(), key.flip(0).contiguous()).flip(0)
+    assert_parity(y, co.cumsum_reverse(xs, key), scale, f"cumsum_reverse n={n} {dist}")
+
+
+@pytest.mark.parametrize("dist", DISTRIBUTIONS)
+@pytest.mark.parametrize("n", SIZES)
+def test_backward(device, n, dist):
+    gc, co = _mods()
+    key = make_keys(n, dist, seed=n + 11)
+    inv, inv_len = co.groups_from_key(key)
+    # near-1 values for the long-run distributions so products do not underflow to 0 everywhere
+    kind = "near1" if dist in ("one_run", "runs3000", "runs9000", "mixed") else "alpha"
+    x = make_values(n, seed=n, kind=kind)
+    cp = co.cumprod_forward(x, key)
+    go = make_values(n, seed=n + 3, kind="normal")
+    got = torch.full((n,), float("nan"), device=device)
+    gc.grouped_cumprod_backward(x.to(device), cp.to(device), go.to(device), inv.to(device), got, inv_len.to(device))
+    scale = co.cumprod_backward_f64(x, cp, go.abs(), inv)
+    if dist in ("one_run", "runs3000", "runs9000", "mixed") and n > 20000:
+        want = co.cumprod_backward_f64(x, cp, go, inv).float()  # literal O(L^2) loop too slow here
+    else:
+        want = co.cumprod_backward(x, cp, go, inv, inv_len)
+    assert_parity(got, want, scale, f"backward n={n} {dist}")
+
+
+def test_zero_param_uses_1e_8(device):
+    """reference: grouped_cumprod_backward.cu:25 — a zero param divides by 1e-8."""
+    gc, co = _mods()
+    x = torch.tensor([0.5, 0.0, 0.25, 0.5, 0.0, 0.0, 2.0])
+    key = torch.tensor([3, 3, 3, 9, 9, 9, 9], dtype=torch.int32)
+    inv, inv_len = co.groups_from_key(key)
+    cp = co.cumprod_forward(x, key)
+    go = torch.tensor([1.0, -2.0, 3.0, 0.5, 1.5, -1.0, 2.0])
+    got = torch.empty(7, device=device)
+    gc.grouped_cumprod_backward(x.to(device), cp.to(device), go.to(device), inv.to(device), got, inv_len.to(device))
+    want = co.cumprod_backward(x, cp, go, inv, inv_len)
+    torch.testing.assert_close(got.cpu(), want, atol=1e-6, rtol=1e-6)
+
+
+def test_empty_is_noop(device):
+    gc, _ = _mods()
+    e = torch.zeros(0, device=device)
+    k = torch.zeros(0, device=device, dtype=torch.int32)
+    gc.grouped_cumprod_forward(e, k, e.clone())
+    gc.grouped_cumsum_forward(e, k, e.clone())
+    gc.grouped_cumprod_backward(e, e, e, k, e.clone(), k)
+
+
+def test_unaligned_views(device):
+    """Contiguous views that start off a 16-byte boundary take the dword path."""
+    gc, co = _mods()
+    n = 20011
+    key = make_keys(n + 3, "poisson8", 1)
+    x = make_values(n + 3, 1)
+    for off in (1, 2, 3):
+        kd, xd = key.to(device)[off : off + n], x.to(device)[off : off + n]
+        assert kd.is_contiguous() and kd.data_ptr() % 16 != 0
+        y = torch.empty(n + 3, device=device)[off : off + n]
+        gc.grouped_cumprod_forward(xd, kd, y)
+        kc, xc = key[off : off + n].contiguous(), x[off : off + n].contiguous()
+        assert_parity(y, co.cumprod_forward(xc, kc), co.cumprod_forward_f64(xc, kc), f"unaligned off={off}")
+
+
+def test_long_groups_use_fallback_and_short_do_not(device):
+    gc, co = _mods()
+    n = 300000
+    key = make_keys(n, "poisson8", 3)
+    x = make_values(n, 3)
+    y = torch.empty(n, device=device)
+    gc.grouped_cumprod_forward(x.to(device), key.to(device), y)
+    assert gc.last_fallback_tiles(device) == 0
+    key = make_keys(n, "runs9000", 3)
+    gc.grouped_cumprod_forward(x.to(device), key.to(device), y)
+    assert gc.last_fallback_tiles(device) > 0
+    assert_parity(y, co.cumprod_forward(x, key), co.cumprod_forward_f64(x, key), "fallback")
+
+
+def test_deterministic(device):
+    gc, _ = _mods()
+    n = 1 << 20
+    key = make_keys(n, "mixed", 5).to(device)
+    x = make_values(n, 5, "normal").to(device)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    gc.grouped_cumsum_forward(x, key, a)
+    gc.grouped_cumsum_forward(x, key, b)
+    assert torch.equal(a, b)
+
+
+def test_argument_errors(device):
+    gc, _ = _mods()
+    x = torch.zeros(8, device=device)
+    k = torch.zeros(8, device=device, dtype=torch.int32)
+    with pytest.raises(RuntimeError):
+        gc.grouped_cumprod_forward(x.double(), k, x)  # dtype, as data_ptr<float>() would throw
+    with pytest.raises(RuntimeError):
+        gc.grouped_cumprod_forward(x, k.long(), x)
+    with pytest.raises(RuntimeError):
+        gc.grouped_cumprod_forward(x[:4], k, x)  # length mismatch
+    with pytest.raises(RuntimeError):
+        gc.grouped_cumprod_forward(x.cpu(), k.cpu(), x.cpu())  # no CPU path
+    with pytest.raises(RuntimeError):
+        gc.grouped_cumprod_forward(x[::2], k[::2], x[::2])  # non-contiguous

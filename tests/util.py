@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests: seeded inputs and the tolerance rule."""
+import torch
+
+TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 fp32 on transmittance and colour"
+
+DISTRIBUTIONS = ("all1", "poisson8", "geo80", "one_run", "runs3000", "runs9000", "mixed")
+
+
+def make_keys(n, dist, seed):
+    """int32 keys of length n whose runs follow `dist`; keys are NOT globally sorted
+    on purpose for some distributions (the contract is runs of equal adjacent keys)."""
+    g = torch.Generator().manual_seed(seed)
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int32)
+    if dist == "all1":
+        lens = torch.ones(n, dtype=torch.long)
+    elif dist == "poisson8":
+        lens = torch.poisson(torch.full((n // 4 + 8,), 8.0), generator=g).long()
+    elif dist == "geo80":
+        u = torch.rand(n // 8 + 8, generator=g).clamp_(min=1e-12)
+        lens = (torch.floor(torch.log(u) / torch.log1p(torch.tensor(-1.0 / 80.0))) + 1).long()
+    elif dist == "one_run":
+        lens = torch.tensor([n])
+    elif dist == "runs3000":
+        lens = torch.randint(2000, 4000, (n // 2000 + 2,), generator=g)
+    elif dist == "runs9000":
+        lens = torch.randint(5000, 13000, (n // 5000 + 2,), generator=g)
+    elif dist == "mixed":
+        a = torch.poisson(torch.full((n // 16 + 8,), 8.0), generator=g).long()
+        b = torch.randint(1, 20000, (n // 16 + 8,), generator=g)
+        pick = torch.rand(n // 16 + 8, generator=g) < 0.01
+        lens = torch.where(pick, b, a)
+    else:
+        raise ValueError(dist)
+    lens = lens[lens > 0]
+    csum = torch.cumsum(lens, 0)
+    k = int(torch.searchsorted(csum, torch.tensor(n)).item()) + 1
+    lens = lens[:k].clone()
+    lens[-1] -= int(csum[k - 1].item()) - n
+    assert int(lens.sum()) == n and int(lens.min()) > 0
+    # alternate a small set of key values so equal keys recur in non-adjacent runs
+    ids = torch.arange(lens.numel())
+    vals = ((ids * 7919) % 1000 + (ids % 2) * 1000003).to(torch.int32)
+    return torch.repeat_interleave(vals, lens)
+
+
+def make_values(n, seed, kind="alpha"):
+    g = torch.Generator().manual_seed(seed + 1)
+    if kind == "alpha":  # 1 - a*g with a ~ sigmoid(N(1.7,2)) as in BASELINE.md
+        a = torch.sigmoid(torch.randn(n, generator=g) * 2.0 + 1.7).clamp_(0.005, 0.995)
+        return 1.0 - a * torch.rand(n, generator=g)
+    if kind == "near1":  # slow decay: long products stay O(1)
+        return 1.0 - 1e-3 * torch.rand(n, generator=g)
+    if kind == "normal":
+        return torch.randn(n, generator=g)
+    raise ValueError(kind)
+
+
+def assert_parity(got, want32, scale, what="", tol=TOL):
+    """|got - want32| <= tol * (1 + scale) elementwise.  `scale` is the magnitude of the
+    quantity with every term taken in absolute value (fp64), i.e. the usual condition
+    scale of a sum; for products it is the value itself."""
+    got = got.detach().cpu().double()
+    want = want32.detach().cpu().double()
+    scale = scale.detach().cpu().double().abs()
+    err = (got - want).abs()
+    bound = tol * (1.0 + scale)
+    bad = err > bound
+    if bad.any():
+        i = int(torch.nonzero(bad)[0])
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.numel()} outside {tol:g}*(1+scale); first at {i}: "
+            f"got {got[i].item():.9g} want {want[i].item():.9g} scale {scale[i].item():.4g}; "
+            f"max err {err.max().item():.3g}"
+        )

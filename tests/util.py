@@ -32,7 +32,7 @@ def make_keys(n, dist, seed):
         lens = torch.where(pick, b, a)
     else:
         raise ValueError(dist)
-    lens = lens[lens > 0]
+    lens = torch.cat([lens[lens > 0], torch.tensor([n])])  # last entry guarantees coverage
     csum = torch.cumsum(lens, 0)
     k = int(torch.searchsorted(csum, torch.tensor(n)).item()) + 1
     lens = lens[:k].clone()

@@ -52,12 +52,13 @@ constexpr int kThreads = 256;      // 4 waves
 constexpr int kWaves = 4;
 constexpr int kRows = 4;           // 16-byte vectors per lane per array
 constexpr int kTile = 1024 * kRows;
-constexpr int kLbChunks = 4;       // look-back window = 4 x 256 elements
+constexpr int kLbChunks = 16;      // look-back window = 16 x 256 elements = one tile
 constexpr int kDescThreads = 1024;
 constexpr int kFixBlocks = 512;
 constexpr int kWsHeaderBytes = 256;
 
 static_assert(kLbChunks * 256 <= kTile, "look-back window must fit in one tile");
+static_assert((kLbChunks - 1) % 3 == 0, "chunks after the first are fetched three at a time");
 
 template <int MODE>
 struct Mode {
@@ -201,7 +202,7 @@ __device__ __forceinline__ i64 logical_tile(i64 b, i64 ntiles, int xcd_remap) {
 // ----------------------------------------------------------------------------
 template <int MODE, bool ALIGNED, bool FULL>
 __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float* s_wv, int* s_wf,
-                                          float* s_tc) {
+                                          float* s_tc, int* s_fh) {
   typedef Mode<MODE> MD;
   constexpr bool REV = MD::kRev;
   constexpr bool BWD = MD::kBwd;
@@ -338,24 +339,38 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     wagg = hmask[r] ? rowtot[r] : M::op(wagg, rowtot[r]);
     whead = whead || (hmask[r] != 0ull);
   }
-  if (lane == 0) { s_wv[w] = wagg; s_wf[w] = whead ? 1 : 0; }
+  // offset (in this wave's chunk, scan order) of the first group head, WT if none
+  int wfh = WT;
+#pragma unroll
+  for (int r = kRows - 1; r >= 0; --r) {
+    if (hmask[r]) {
+      const int hl = __builtin_ctzll(hmask[r]);
+      const unsigned ob = (unsigned)__builtin_amdgcn_readlane((int)openbits, hl);
+      wfh = r * 256 + hl * 4 + __builtin_popcount((ob >> (4 * r)) & 0xfu);
+    }
+  }
+  if (lane == 0) { s_wv[w] = wagg; s_wf[w] = whead ? 1 : 0; s_fh[w] = wfh; }
 
   // ---- look-back (wave 0): carry entering the tile -------------------------
+  // Chunk 0 (256 elements) was loaded speculatively with the tile.  If the group
+  // reaches further back, chunks are fetched three at a time (one dependent
+  // round trip per 768 elements) up to one full tile.
   if (w == 0) {
     float tc = id;
     int unresolved = 0;
     if (do_lb) {
       const int k0 = __builtin_amdgcn_readfirstlane(kk[0].x);
-      for (int j = 0;; ++j) {
-        // items in scan-order distance: item k of this lane is at distance j*256+lane*4+k+1
-        const float4_t lv = REV ? lbv : to_scan_order<true>(lbv);
-        const int4_t lk = REV ? lbk : to_scan_order<true>(lbk);
+      // returns true when the look-back is finished (group start found, or array end)
+      auto process = [&](float4_t cv, int4_t ck, i64 cp, int j) -> bool {
+        // scan-order distance of item k of this lane: j*256 + lane*4 + k + 1
+        const float4_t lv = REV ? cv : to_scan_order<true>(cv);
+        const int4_t lk = REV ? ck : to_scan_order<true>(ck);
         bool c0, c1, c2, c3;
         if (!REV) {
           c0 = lk.x == k0; c1 = lk.y == k0; c2 = lk.z == k0; c3 = lk.w == k0;
         } else {
-          c0 = (lbp + 0 < n) && lk.x == k0; c1 = (lbp + 1 < n) && lk.y == k0;
-          c2 = (lbp + 2 < n) && lk.z == k0; c3 = (lbp + 3 < n) && lk.w == k0;
+          c0 = (cp + 0 < n) && lk.x == k0; c1 = (cp + 1 < n) && lk.y == k0;
+          c2 = (cp + 2 < n) && lk.z == k0; c3 = (cp + 3 < n) && lk.w == k0;
         }
         float p = id;
         bool full = false;
@@ -364,22 +379,34 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         const int L = (fm == ~0ull) ? 64 : __builtin_ctzll(~fm);
         const float contrib = (lane <= L) ? p : id;
         tc = M::op(wave_reduce<MD::kMul>(contrib), tc);
-        if (L < 64) break;  // group start found inside this chunk
+        if (L < 64) return true;  // group start found inside this chunk
         const bool more = REV ? (base + kTile + (i64)(j + 1) * 256 < n) : (base - (i64)(j + 1) * 256 > 0);
-        if (!more) break;   // reached the end of the array: resolved
-        if (j + 1 == kLbChunks) { unresolved = 1; break; }
-        lbp = REV ? (lbp + 256) : (lbp - 256);
-        if (!REV) {
-          lbk = ld4<ALIGNED>(a.key + lbp);
-          if constexpr (BWD) lbv = ld4<ALIGNED>(a.in2 + lbp) * ld4<ALIGNED>(a.in1 + lbp);
-          else lbv = ld4<ALIGNED>(a.in0 + lbp);
-        } else {
-          lbk = ld4_guard(a.key, lbp, n, 0);
-          if constexpr (BWD) lbv = ld4_guard(a.in2, lbp, n, 0.0f) * ld4_guard(a.in1, lbp, n, 0.0f);
-          else lbv = ld4_guard(a.in0, lbp, n, id);
+        return !more;             // reached the end of the array: resolved
+      };
+      bool done = process(lbv, lbk, lbp, 0);
+      for (int j = 1; !done && j < kLbChunks; j += 3) {
+        float4_t cv[3];
+        int4_t ck[3];
+        i64 cp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          cp[c] = REV ? (base + kTile + (i64)(j + c) * 256 + lane * 4) : (base - ((i64)(j + c) * 256 + lane * 4 + 4));
+          if (!REV) {
+            ck[c] = ld4<ALIGNED>(a.key + cp[c]);
+            if constexpr (BWD) cv[c] = ld4<ALIGNED>(a.in2 + cp[c]) * ld4<ALIGNED>(a.in1 + cp[c]);
+            else cv[c] = ld4<ALIGNED>(a.in0 + cp[c]);
+          } else {
+            ck[c] = ld4_guard(a.key, cp[c], n, 0);
+            if constexpr (BWD) cv[c] = ld4_guard(a.in2, cp[c], n, 0.0f) * ld4_guard(a.in1, cp[c], n, 0.0f);
+            else cv[c] = ld4_guard(a.in0, cp[c], n, id);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (!done) done = process(cv[c], ck[c], cp[c], j + c);
         }
       }
-      if (unresolved) tc = id;  // the fix-up kernel folds the true prefix in later
+      if (!done) { unresolved = 1; tc = id; }  // the fix-up kernel folds the true prefix in later
     }
     if (lane == 0) { s_tc[0] = tc; s_wf[kWaves] = unresolved; }
   }
@@ -423,9 +450,14 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
 
   // ---- tile descriptor + unresolved queue (fallback path only reads them) ----
   if (a.ntiles > 1 && w == kWaves - 1 && lane == 0) {
+    int first_head = kTile;  // elements [0, first_head) of the tile (scan order) take the carry-in
+#pragma unroll
+    for (int j = kWaves - 1; j >= 0; --j)
+      if (s_wf[j]) first_head = j * WT + s_fh[j];
     uint2 d;
     d.x = __builtin_bit_cast(unsigned, R);                 // inclusive aggregate of the tile's tail group
-    d.y = (unresolved && !tile_head) ? 1u : 0u;           // open: depends on the (unknown) carry-in
+    // bit 0 = open (aggregate depends on the still unknown carry-in), bits 1.. = first head offset
+    d.y = ((unresolved && !tile_head) ? 1u : 0u) | ((unsigned)first_head << 1);
     a.desc[lt] = d;
     if (unresolved) {
       const unsigned slot = atomicAdd(a.hdr, 1u);
@@ -439,10 +471,11 @@ __global__ __launch_bounds__(kThreads) void gcp_scan_main(const ScanArgs a) {
   __shared__ float s_wv[kWaves];
   __shared__ int s_wf[kWaves + 1];
   __shared__ float s_tc[1];
+  __shared__ int s_fh[kWaves];
   const i64 lt = logical_tile((i64)blockIdx.x, a.ntiles, a.xcd_remap);
   const i64 pt = Mode<MODE>::kRev ? (a.ntiles - 1 - lt) : lt;
-  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true>(a, lt, s_wv, s_wf, s_tc);
-  else scan_tile<MODE, ALIGNED, false>(a, lt, s_wv, s_wf, s_tc);
+  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  else scan_tile<MODE, ALIGNED, false>(a, lt, s_wv, s_wf, s_tc, s_fh);
 }
 
 // ----------------------------------------------------------------------------
@@ -472,11 +505,17 @@ __global__ __launch_bounds__(kDescThreads) void gcp_desc_scan(const ScanArgs a) 
   const i64 t1 = (t0 + per < a.ntiles) ? (t0 + per) : a.ntiles;
   float v = id;
   bool f = false;
-  for (i64 t = t0; t < t1; ++t) {
-    const uint2 d = a.desc[t];
-    const float g = __builtin_bit_cast(float, d.x);
-    if (d.y) v = M::op(v, g);
-    else { v = g; f = true; }
+  constexpr int kBatch = 8;  // independent loads in flight per thread
+  for (i64 t = t0; t < t1; t += kBatch) {
+    uint2 d[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) d[u] = (t + u < t1) ? a.desc[t + u] : make_uint2(__builtin_bit_cast(unsigned, id), 1u);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const float g = __builtin_bit_cast(float, d[u].x);
+      if (d[u].y & 1u) v = M::op(v, g);
+      else { v = g; f = true; }
+    }
   }
   const unsigned long long mask = __ballot(f);
   const unsigned long long upto = mask & (~0ull >> (63 - lane));
@@ -489,11 +528,16 @@ __global__ __launch_bounds__(kDescThreads) void gcp_desc_scan(const ScanArgs a) 
   float wc = id;
   for (int j = 0; j < w; ++j) wc = s_f[j] ? s_v[j] : M::op(wc, s_v[j]);
   float c = open_before ? M::op(wc, ex) : ex;
-  for (i64 t = t0; t < t1; ++t) {
-    a.carry[t] = c;
-    const uint2 d = a.desc[t];
-    const float g = __builtin_bit_cast(float, d.x);
-    c = d.y ? M::op(c, g) : g;
+  for (i64 t = t0; t < t1; t += kBatch) {
+    uint2 d[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) d[u] = (t + u < t1) ? a.desc[t + u] : make_uint2(__builtin_bit_cast(unsigned, id), 1u);
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      if (t + u < t1) a.carry[t + u] = c;
+      const float g = __builtin_bit_cast(float, d[u].x);
+      c = (d[u].y & 1u) ? M::op(c, g) : g;
+    }
   }
 }
 
@@ -506,7 +550,6 @@ __global__ __launch_bounds__(kThreads) void gcp_fixup(const ScanArgs a) {
   typedef Mode<MODE> MD;
   constexpr bool REV = MD::kRev;
   typedef Monoid<MD::kMul> M;
-  __shared__ int s_first;
   const unsigned cnt = a.hdr[1];
   const i64 n = a.n;
   for (unsigned i = blockIdx.x; i < cnt; i += gridDim.x) {
@@ -514,21 +557,7 @@ __global__ __launch_bounds__(kThreads) void gcp_fixup(const ScanArgs a) {
     const float C = a.carry[lt];
     const i64 pt = REV ? (a.ntiles - 1 - lt) : lt;
     const i64 base = pt * (i64)kTile;
-    if (threadIdx.x == 0) s_first = kTile;
-    __syncthreads();
-    // logical offset q in [0, kTile): physical p = fwd base+q, rev base+kTile-1-q
-    int myfirst = kTile;
-    for (int q = threadIdx.x; q < kTile; q += kThreads) {
-      const i64 p = REV ? (base + kTile - 1 - q) : (base + q);
-      if (p >= n) continue;
-      const i64 pp = REV ? (p + 1) : (p - 1);
-      const bool pex = REV ? (pp < n) : (pp >= 0);
-      const bool head = !pex || (a.key[p] != a.key[pp]);
-      if (head && q < myfirst) myfirst = q;
-    }
-    if (myfirst < kTile) atomicMin(&s_first, myfirst);
-    __syncthreads();
-    const int first = s_first;
+    const int first = (int)(a.desc[lt].y >> 1);
     for (int q = threadIdx.x; q < first; q += kThreads) {
       const i64 p = REV ? (base + kTile - 1 - q) : (base + q);
       if (p >= n) continue;
@@ -539,7 +568,6 @@ __global__ __launch_bounds__(kThreads) void gcp_fixup(const ScanArgs a) {
         a.out[p] = M::op(C, a.out[p]);
       }
     }
-    __syncthreads();
   }
 }
 

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: splat-pixel pairs blended per second, grouped cumprod forward + backward.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic pair list resident in HBM:
+grouped_cumprod_forward (12 B/pair) then grouped_cumprod_backward (20 B/pair) — the two
+kernels BASELINE.json's metric is quoted on.  Workload at every N: each rank
+owns one cfg3-sized image band (1920x1080 pixels, mean 80 splats/pixel, heavy-tailed, M ~ 1.66e8
+pairs); pixel groups are independent so there is NO data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the backward scan):
+algorithmic bytes (20 B x pairs per launch) / its mean duration measured with HIP events on the
+launch stream inside the timed region.  `cpu_baseline` times the oracle's sequential C port of the
+same two ops on the host cores, on a bounded sample of the same pair list (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_FWD, BYTES_BWD = 12, 20  # algorithmic bytes per pair
+
+
+def cpu_baseline(p, sample_pairs):
+    """Oracle (sequential C port of the reference kernels) on the first groups of the pair list."""
+    import torch
+
+    from oracle import c_oracle as co
+
+    inv_len = p.inv_len.cpu()
+    g = int(torch.searchsorted(inv_len, torch.tensor(sample_pairs, dtype=inv_len.dtype)).item())
+    g = max(1, min(g, inv_len.numel()))
+    s = int(inv_len[g - 1].item())
+    x, key, inv, go = (t[:s].cpu().contiguous() for t in (p.x, p.key, p.inv, p.grad_out))
+    il = inv_len[:g].contiguous()
+    co.cumprod_forward(x[:1024].contiguous(), key[:1024].contiguous())  # load the library
+    t0 = time.perf_counter()
+    y = co.cumprod_forward(x, key)
+    t1 = time.perf_counter()
+    co.cumprod_backward(x, y, go, inv, il)
+    t2 = time.perf_counter()
+    return {
+        "value": s / (t2 - t0),
+        "unit": "pairs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {g} pixel groups = {s} pairs of the same pair list; oracle/gcp_oracle.c "
+        f"(sequential fp32, literal O(L^2) backward loop of the reference); fwd {1e3*(t1-t0):.1f} ms, "
+        f"bwd {1e3*(t2-t1):.1f} ms; host has {os.cpu_count()} cpus",
+    }
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[workload][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3", help="cfg2 | cfg3 | cfg5band (one 8th of the 4K frame)")
+    ap.add_argument("--cpu-sample", type=int, default=64_000_000, help="pairs in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import grouped_cumprod as gc
+    from simplegaussiansplat_tk71_amd import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(
+                f"--gpus {args.gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus}"
+            )
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    # this rank's band of the frame; bands are independent pair lists (no exchange on the scan path)
+    if args.workload == "cfg5band":
+        rows = synthetic.CONFIGS["cfg5"]["height"] // 8
+        p = synthetic.make_config("cfg5", seed=rank, device=dev, rows=rows, row_start=rank * rows)
+        wl = f"cfg5 band: 3840x{rows} rows of the 3840x2160 / 5M-Gaussian frame, mean 100 splats/pixel (deep)"
+    else:
+        c = synthetic.CONFIGS[args.workload]
+        p = synthetic.make_config(args.workload, seed=rank, device=dev, row_start=rank * c["height"])
+        wl = (
+            f"{args.workload}: {c['width']}x{c['height']}, {c['gaussians']} Gaussians, mean {c['mean_depth']:g} "
+            f"splats/pixel ({'deep heavy-tailed lists' if c['deep'] else 'Poisson'})"
+        )
+    m = p.n_pairs
+    y = torch.empty_like(p.x)
+    gin = torch.empty_like(p.x)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(e=None):
+        if e is not None:
+            e[0].record()
+        gc.grouped_cumprod_forward(p.x, p.key, y)
+        if e is not None:
+            e[1].record()
+        gc.grouped_cumprod_backward(p.x, y, p.grad_out, p.inv, gin, p.inv_len)
+        if e is not None:
+            e[2].record()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    t_fwd = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3  # seconds per launch
+    t_bwd = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps * 1e-3
+    fallback = gc.last_fallback_tiles(dev)
+
+    stats = torch.tensor([elapsed, float(m)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        msum = stats[1:].clone()
+        dist.all_reduce(msum, op=dist.ReduceOp.SUM)
+        elapsed, total_pairs = float(tmax.item()), float(msum.item())
+    else:
+        total_pairs = float(m)
+
+    if rank == 0:
+        ach = BYTES_BWD * m / t_bwd / 1e9
+        out = {
+            "metric": "splat-pixel pairs blended per second (grouped cumprod fwd+bwd)",
+            "value": total_pairs * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": wl,
+                "pairs_per_gpu": m,
+                "pixel_groups_per_gpu": p.n_groups,
+                "sharding": "one image band per GPU, no data-path collective" if world > 1 else "single GPU",
+                "bytes_per_pair": BYTES_FWD + BYTES_BWD,
+                "aggregate_algorithmic_GBps": (BYTES_FWD + BYTES_BWD) * total_pairs * args.steps / elapsed / 1e9,
+                "fallback_tiles_last_launch": fallback,
+            },
+            "roofline": {
+                "kernel": "gcp_scan_main<CUMPROD_BWD> (grouped_cumprod_backward)",
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS,
+                "traffic": pmc_traffic("cumprod_bwd", args.workload),
+                "avg_launch_us": t_bwd * 1e6,
+                "algorithmic_bytes_per_launch": BYTES_BWD * m,
+                "forward": {
+                    "kernel": "gcp_scan_main<CUMPROD_FWD> (grouped_cumprod_forward)",
+                    "achieved": BYTES_FWD * m / t_fwd / 1e9,
+                    "frac": BYTES_FWD * m / t_fwd / 1e9 / HBM_PEAK_GBPS,
+                    "avg_launch_us": t_fwd * 1e6,
+                    "traffic": pmc_traffic("cumprod_fwd", args.workload),
+                },
+                "fwd_plus_bwd_frac": (BYTES_FWD + BYTES_BWD) * m / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS,
+            },
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(p, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,9 +23,12 @@
 //     neighbouring tile is being streamed at the same time).  Groups that reach
 //     further back than the window are rare for per-pixel splat lists; they are
 //     handled exactly by a descriptor fallback: every tile stores {aggregate,
-//     open} (8 B / tile), unresolved tiles are queued, a one-block kernel scans
-//     the descriptors and a fix-up kernel folds the missing prefix into the
-//     queued tiles.  No spinning, no value-carrying atomics: deterministic.
+//     open, unresolved, first head offset} (8 B / tile); ONE follow-up kernel
+//     (<= 256 blocks, each owning a contiguous range of tiles) returns at once
+//     when its range holds no unresolved tile, and otherwise scans the
+//     descriptors and folds the missing prefix into the leading elements of the
+//     unresolved tiles.  Stateless, no spinning, no value-carrying atomics:
+//     deterministic, and the workspace needs no initialisation.
 //   * The backward (a3) is the same machinery run in reverse index order on
 //     w[i] = grad_out[i] * cumprod[i] with the division by p'_j fused into the
 //     store: one O(n) pass, 20 B / element.
@@ -50,11 +53,16 @@ enum : int { M_CUMPROD_FWD = 0, M_CUMSUM_FWD = 1, M_CUMPROD_BWD = 2, M_CUMSUM_RE
 
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kWaves = 4;
-constexpr int kRows = 4;           // 16-byte vectors per lane per array
+#ifndef GCP_ROWS
+#define GCP_ROWS 4
+#endif
+#ifndef GCP_XCD_REMAP_DEFAULT
+#define GCP_XCD_REMAP_DEFAULT 1
+#endif
+constexpr int kRows = GCP_ROWS;    // 16-byte vectors per lane per array
 constexpr int kTile = 1024 * kRows;
-constexpr int kLbChunks = 16;      // look-back window = 16 x 256 elements = one tile
-constexpr int kDescThreads = 1024;
-constexpr int kFixBlocks = 512;
+constexpr int kLbChunks = ((kTile / 256 - 1) / 3) * 3 + 1;  // look-back window in 256-element chunks (16 = one tile at kRows 4)
+constexpr int kFixBlocks = 256;     // upper bound of the fallback kernel's grid
 constexpr int kWsHeaderBytes = 256;
 
 static_assert(kLbChunks * 256 <= kTile, "look-back window must fit in one tile");
@@ -81,10 +89,8 @@ struct ScanArgs {
   float* out;
   i64 n;
   i64 ntiles;
-  uint2* desc;        // per logical tile: {aggregate bits, open}
-  float* carry;       // per logical tile: prefix entering the tile (fallback only)
-  unsigned* list;     // queue of unresolved logical tiles
-  unsigned* hdr;      // [0] queue length, [1] snapshot for fix-up, [2] last count
+  uint2* desc;        // per logical tile: {aggregate bits, open | unresolved<<1 | first_head<<2}
+  unsigned* hdr;      // [2] = unresolved tiles of the last launch (introspection only)
   int xcd_remap;
 };
 
@@ -448,7 +454,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     R = hmask[r] ? rowtot[r] : M::op(R, rowtot[r]);
   }
 
-  // ---- tile descriptor + unresolved queue (fallback path only reads them) ----
+  // ---- tile descriptor (only the fallback kernel reads it) -------------------
+  if (lt == 0 && w == kWaves - 1 && lane == 0) a.hdr[2] = 0;  // introspection counter, re-armed per launch
   if (a.ntiles > 1 && w == kWaves - 1 && lane == 0) {
     int first_head = kTile;  // elements [0, first_head) of the tile (scan order) take the carry-in
 #pragma unroll
@@ -456,13 +463,10 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       if (s_wf[j]) first_head = j * WT + s_fh[j];
     uint2 d;
     d.x = __builtin_bit_cast(unsigned, R);                 // inclusive aggregate of the tile's tail group
-    // bit 0 = open (aggregate depends on the still unknown carry-in), bits 1.. = first head offset
-    d.y = ((unresolved && !tile_head) ? 1u : 0u) | ((unsigned)first_head << 1);
+    // bit 0 = open (aggregate depends on the still unknown carry-in), bit 1 = unresolved,
+    // bits 2.. = first head offset
+    d.y = ((unresolved && !tile_head) ? 1u : 0u) | (unresolved ? 2u : 0u) | ((unsigned)first_head << 2);
     a.desc[lt] = d;
-    if (unresolved) {
-      const unsigned slot = atomicAdd(a.hdr, 1u);
-      a.list[slot] = (unsigned)lt;
-    }
   }
 }
 
@@ -479,95 +483,107 @@ __global__ __launch_bounds__(kThreads) void gcp_scan_main(const ScanArgs a) {
 }
 
 // ----------------------------------------------------------------------------
-// Fallback kernel 2: one block scans the tile descriptors (only if the queue
-// is non-empty) and writes the prefix entering every tile.
-// ----------------------------------------------------------------------------
-template <bool MUL>
-__global__ __launch_bounds__(kDescThreads) void gcp_desc_scan(const ScanArgs a) {
-  typedef Monoid<MUL> M;
-  const float id = M::identity();
-  __shared__ float s_v[kDescThreads / 64];
-  __shared__ int s_f[kDescThreads / 64];
-  __shared__ unsigned s_cnt;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) {
-    const unsigned c = a.hdr[0];
-    s_cnt = c;
-    a.hdr[1] = c;  // snapshot consumed by the fix-up kernel
-    a.hdr[2] = c;  // introspection: gcp_last_fallback_tiles
-    a.hdr[0] = 0;  // ready for the next call
-  }
-  __syncthreads();
-  if (s_cnt == 0) return;
-
-  const i64 per = (a.ntiles + kDescThreads - 1) / kDescThreads;
-  const i64 t0 = (i64)tid * per;
-  const i64 t1 = (t0 + per < a.ntiles) ? (t0 + per) : a.ntiles;
-  float v = id;
-  bool f = false;
-  constexpr int kBatch = 8;  // independent loads in flight per thread
-  for (i64 t = t0; t < t1; t += kBatch) {
-    uint2 d[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) d[u] = (t + u < t1) ? a.desc[t + u] : make_uint2(__builtin_bit_cast(unsigned, id), 1u);
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const float g = __builtin_bit_cast(float, d[u].x);
-      if (d[u].y & 1u) v = M::op(v, g);
-      else { v = g; f = true; }
-    }
-  }
-  const unsigned long long mask = __ballot(f);
-  const unsigned long long upto = mask & (~0ull >> (63 - lane));
-  const int h = upto ? (63 - __clzll(upto)) : -1;
-  const float inc = wave_seg_scan<MUL>(v, h, lane);
-  float ex = dpp_f<0x138, 0xf>(id, inc);
-  const bool open_before = (mask & ((1ull << lane) - 1ull)) == 0ull;
-  if (lane == 63) { s_v[w] = inc; s_f[w] = (mask != 0ull) ? 1 : 0; }
-  __syncthreads();
-  float wc = id;
-  for (int j = 0; j < w; ++j) wc = s_f[j] ? s_v[j] : M::op(wc, s_v[j]);
-  float c = open_before ? M::op(wc, ex) : ex;
-  for (i64 t = t0; t < t1; t += kBatch) {
-    uint2 d[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) d[u] = (t + u < t1) ? a.desc[t + u] : make_uint2(__builtin_bit_cast(unsigned, id), 1u);
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      if (t + u < t1) a.carry[t + u] = c;
-      const float g = __builtin_bit_cast(float, d[u].x);
-      c = (d[u].y & 1u) ? M::op(c, g) : g;
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// Fallback kernel 3: fold the prefix into the leading (pre-first-head) elements
-// of every queued tile.
+// Fallback kernel (one launch after every multi-tile scan).  Block b owns the
+// contiguous tile range [b*per, (b+1)*per).  Common case: no tile of the range
+// is unresolved -> one coalesced descriptor read and return.  Otherwise wave 0
+//   1. walks the descriptors back from the range start until a closed tile to
+//      get the prefix entering the range (64 descriptors per step),
+//   2. runs a segmented scan over the range, 64 tiles per step, which yields
+//      the prefix entering every tile,
+// and all 4 waves fold that prefix into elements [0, first_head) of every
+// unresolved tile.  Cost is O(ntiles/64) steps per block even for one group
+// spanning the whole array.
 // ----------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void gcp_fixup(const ScanArgs a) {
+__global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
   typedef Mode<MODE> MD;
   constexpr bool REV = MD::kRev;
   typedef Monoid<MD::kMul> M;
-  const unsigned cnt = a.hdr[1];
+  const float id = M::identity();
+  __shared__ int s_any;
+  __shared__ int s_cnt;
+  __shared__ int s_tile[64];
+  __shared__ float s_carry[64];
+  __shared__ int s_first[64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const i64 n = a.n;
-  for (unsigned i = blockIdx.x; i < cnt; i += gridDim.x) {
-    const i64 lt = a.list[i];
-    const float C = a.carry[lt];
-    const i64 pt = REV ? (a.ntiles - 1 - lt) : lt;
-    const i64 base = pt * (i64)kTile;
-    const int first = (int)(a.desc[lt].y >> 1);
-    for (int q = threadIdx.x; q < first; q += kThreads) {
-      const i64 p = REV ? (base + kTile - 1 - q) : (base + q);
-      if (p >= n) continue;
-      if (MD::kBwd) {
-        const float x = a.in0[p];
-        a.out[p] = a.out[p] + C / (x != 0.0f ? x : 1e-8f);
-      } else {
-        a.out[p] = M::op(C, a.out[p]);
+  const i64 per = (a.ntiles + gridDim.x - 1) / gridDim.x;
+  const i64 r0 = (i64)blockIdx.x * per;
+  const i64 r1 = (r0 + per < a.ntiles) ? (r0 + per) : a.ntiles;
+  if (r0 >= r1) return;
+
+  if (tid == 0) s_any = 0;
+  __syncthreads();
+  int mine = 0;
+  for (i64 t = r0 + tid; t < r1; t += kThreads) mine += (int)((a.desc[t].y >> 1) & 1u);
+  if (mine) atomicAdd(&s_any, mine);
+  __syncthreads();
+  const int n_unres = s_any;
+  if (n_unres == 0) return;
+  if (tid == 0) atomicAdd(a.hdr + 2, (unsigned)n_unres);
+
+  // 1. prefix entering tile r0 = inclusive aggregate of tile r0-1 (wave 0, all lanes hold C)
+  float C = id;
+  if (w == 0) {
+    for (i64 t = r0; t > 0; t -= 64) {
+      const i64 idx = t - 1 - lane;  // lane 0 = nearest predecessor
+      uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 0u);  // before the array: closed, identity
+      if (idx >= 0) d = a.desc[idx];
+      const bool closed = (d.y & 1u) == 0u;
+      const unsigned long long cm = __ballot(closed);
+      const int lc = cm ? __builtin_ctzll(cm) : 64;
+      const float contrib = (lane <= lc) ? __builtin_bit_cast(float, d.x) : id;
+      C = M::op(wave_reduce<MD::kMul>(contrib), C);
+      if (lc < 64) break;
+    }
+  }
+
+  // 2. range scan, 64 tiles per step
+  for (i64 c0 = r0; c0 < r1; c0 += 64) {
+    if (w == 0) {
+      const i64 t = c0 + lane;
+      uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 1u);  // past the range: open, identity, resolved
+      if (t < r1) d = a.desc[t];
+      const bool closed = (d.y & 1u) == 0u;
+      const bool unres = ((d.y >> 1) & 1u) != 0u;
+      const unsigned long long cm = __ballot(closed);
+      const unsigned long long upto = cm & (~0ull >> (63 - lane));
+      const int h = upto ? (63 - __clzll(upto)) : -1;
+      const float inc = wave_seg_scan<MD::kMul>(__builtin_bit_cast(float, d.x), h, lane);
+      const float ex = dpp_f<0x138, 0xf>(id, inc);
+      const bool open_before = (cm & ((1ull << lane) - 1ull)) == 0ull;
+      const float cin = open_before ? M::op(C, ex) : ex;  // prefix entering tile t
+      const unsigned long long um = __ballot(unres);
+      if (unres) {
+        const int slot = __builtin_popcountll(um & ((1ull << lane) - 1ull));
+        s_tile[slot] = (int)(t - c0);
+        s_carry[slot] = cin;
+        s_first[slot] = (int)(d.y >> 2);
+      }
+      if (lane == 0) s_cnt = __builtin_popcountll(um);
+      const float tot = readlane_f(inc, 63);
+      C = cm ? tot : M::op(C, tot);
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    for (int i = 0; i < cnt; ++i) {
+      const i64 lt = c0 + s_tile[i];
+      const float cin = s_carry[i];
+      const int first = s_first[i];
+      const i64 pt = REV ? (a.ntiles - 1 - lt) : lt;
+      const i64 base = pt * (i64)kTile;
+      for (int q = tid; q < first; q += kThreads) {
+        const i64 p = REV ? (base + kTile - 1 - q) : (base + q);
+        if (p >= n) continue;
+        if (MD::kBwd) {
+          const float x = a.in0[p];
+          a.out[p] = a.out[p] + cin / (x != 0.0f ? x : 1e-8f);
+        } else {
+          a.out[p] = M::op(cin, a.out[p]);
+        }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -612,9 +628,7 @@ inline i64 ws_tiles(i64 n) { return (n + 1023) / 1024; }  // upper bound for any
 size_t ws_bytes_for(i64 n) {
   const i64 t = ws_tiles(n > 0 ? n : 0);
   size_t b = kWsHeaderBytes;
-  b += ((size_t)t * 8 + 255) / 256 * 256;   // desc
-  b += ((size_t)t * 4 + 255) / 256 * 256;   // carry
-  b += ((size_t)t * 4 + 255) / 256 * 256;   // list
+  b += ((size_t)t * 8 + 255) / 256 * 256;   // tile descriptors
   return b;
 }
 
@@ -676,10 +690,9 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out;
   a.n = n; a.ntiles = ntiles;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
-  a.desc = (uint2*)p; p += ((size_t)t * 8 + 255) / 256 * 256;
-  a.carry = (float*)p; p += ((size_t)t * 4 + 255) / 256 * 256;
-  a.list = (unsigned*)p;
-  static const int xcd_remap = env_int("GCP_XCD_REMAP", 1);
+  a.desc = (uint2*)p;
+  (void)t;
+  static const int xcd_remap = env_int("GCP_XCD_REMAP", GCP_XCD_REMAP_DEFAULT);
   a.xcd_remap = xcd_remap;
 
   uintptr_t al = (uintptr_t)in0 | (uintptr_t)key | (uintptr_t)out;
@@ -691,9 +704,8 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   else hipLaunchKernelGGL((gcp_scan_main<MODE, false>), grid, block, 0, stream, a);
   GCP_HIP(hipGetLastError());
   if (ntiles > 1) {
-    hipLaunchKernelGGL((gcp_desc_scan<Mode<MODE>::kMul>), dim3(1), dim3(kDescThreads), 0, stream, a);
-    GCP_HIP(hipGetLastError());
-    hipLaunchKernelGGL((gcp_fixup<MODE>), dim3(kFixBlocks), dim3(kThreads), 0, stream, a);
+    const unsigned fb = (unsigned)(ntiles < kFixBlocks ? ntiles : kFixBlocks);
+    hipLaunchKernelGGL((gcp_fallback<MODE>), dim3(fb), dim3(kThreads), 0, stream, a);
     GCP_HIP(hipGetLastError());
   }
   return GCP_OK;

@@ -159,3 +159,33 @@ def test_argument_errors(device):
         gc.grouped_cumprod_forward(x.cpu(), k.cpu(), x.cpu())  # no CPU path
     with pytest.raises(RuntimeError):
         gc.grouped_cumprod_forward(x[::2], k[::2], x[::2])  # non-contiguous
+
+
+@pytest.mark.parametrize("dist", ["one_run", "runs9000", "mixed", "geo80"])
+def test_fallback_many_tiles(device, dist):
+    """> 256 tiles so every block of the fallback kernel owns a multi-tile range, with groups that
+    span many tiles (and, for one_run, the whole array)."""
+    gc, co = _mods()
+    n = 3_000_017
+    key = make_keys(n, dist, seed=17)
+    inv, inv_len = co.groups_from_key(key)
+    kd = key.to(device)
+    x = make_values(n, 17, "near1")
+    y = torch.empty(n, device=device)
+    gc.grouped_cumprod_forward(x.to(device), kd, y)
+    if dist != "geo80":
+        assert gc.last_fallback_tiles(device) > 0
+    want = co.cumprod_forward(x, key)
+    assert_parity(y, want, co.cumprod_forward_f64(x, key), f"cumprod {dist}")
+
+    xs = make_values(n, 18, "normal")
+    gc.grouped_cumsum_forward(xs.to(device), kd, y)
+    assert_parity(y, co.cumsum_forward(xs, key), co.cumsum_forward_f64(xs.abs(), key), f"cumsum {dist}")
+    gc.grouped_cumsum_reverse(xs.to(device), kd, y)
+    scale = co.cumsum_forward_f64(xs.abs().flip(0).contiguous(), key.flip(0).contiguous()).flip(0)
+    assert_parity(y, co.cumsum_reverse(xs, key), scale, f"cumsum_reverse {dist}")
+
+    go = make_values(n, 19, "normal")
+    gc.grouped_cumprod_backward(x.to(device), want.to(device), go.to(device), inv.to(device), y, inv_len.to(device))
+    w64 = co.cumprod_backward_f64(x, want, go, inv)
+    assert_parity(y, w64.float(), co.cumprod_backward_f64(x, want, go.abs(), inv), f"backward {dist}")

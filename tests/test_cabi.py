@@ -1,0 +1,87 @@
+"""The C-ABI library builds, loads, and exports every symbol include/grouped_cumprod_hip.h declares.
+No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "grouped_cumprod_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    from simplegaussiansplat_tk71_amd import _build, _lib
+
+    path = _build.build_hip_library()
+    assert os.path.exists(path)
+    lib = _lib.load()
+    assert lib.gcp_abi_version() == _lib.ABI_VERSION == 1
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from simplegaussiansplat_tk71_amd import _build, _lib
+
+    names = _declared()
+    assert len(names) >= 12
+    lib = ctypes.CDLL(_build.build_hip_library())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes binding and header disagree"
+
+
+def test_pure_host_entry_points():
+    from simplegaussiansplat_tk71_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gcp_tile_elems() == 4096
+    assert lib.gcp_workspace_bytes(0) >= 256
+    prev = 0
+    for n in (1, 4096, 4097, 1 << 20, 1 << 28, 1 << 31):
+        b = lib.gcp_workspace_bytes(n)
+        assert b >= prev and b % 256 == 0
+        prev = b
+    assert lib.gcp_workspace_bytes(1 << 28) < (1 << 28) // 16  # descriptors are < 1% of one array
+    assert lib.gcp_status_string(0) == b"ok"
+    assert b"argument" in lib.gcp_status_string(1)
+    assert lib.gcp_last_hip_error() == 0
+
+
+def test_argument_validation_needs_no_gpu():
+    """Invalid-argument paths return before any HIP call."""
+    from simplegaussiansplat_tk71_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gcp_cumprod_forward(None, None, None, 0, None, 0, None) == 0  # n == 0 is a no-op
+    assert lib.gcp_cumprod_forward(None, None, None, 8, None, 0, None) == 1
+    assert lib.gcp_cumprod_forward(None, None, None, -1, None, 0, None) == 1
+    assert lib.gcp_cumsum_forward(None, None, None, 8, None, 0, None) == 1
+    assert lib.gcp_cumprod_backward(None, None, None, None, None, None, 8, 1, None, 0, None) == 1
+    assert lib.gcp_workspace_init(None, 0, None) == 2
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never route through oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "simplegaussiansplat_tk71_amd")
+    files = [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")]
+    files += [os.path.join(ROOT, "grouped_cumprod.py"), os.path.join(ROOT, "cuda_kernel.py"), os.path.join(ROOT, "setup.py")]
+    for f in files:
+        src = open(f).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_cpu_tensors_are_rejected():
+    import pytest
+    import torch
+
+    import grouped_cumprod as gc
+
+    x = torch.ones(4)
+    k = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gc.grouped_cumprod_forward(x, k, x.clone())
+    with pytest.raises(RuntimeError, match="scalar type"):
+        gc.grouped_cumprod_forward(x, k.long(), x.clone())

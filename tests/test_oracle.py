@@ -1,0 +1,164 @@
+"""CPU tests that pin the oracle: reference known-answer vectors, golden vectors produced by the
+reference's own kernels (tests/golden/), the live host build of the reference where present, and
+the pure-PyTorch torch.cumprod statement."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import torch_path as tp
+from oracle import wrappers as ow
+from tests.util import make_keys, make_values
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_kat_cuda_test_py():
+    """reference: cuda_test.py:19-34; expected backward is printed at :34."""
+    param = torch.tensor([0.4, 0.2, 0.1, 0.8, 0.2])
+    index = torch.tensor([0, 0, 1, 1, 2], dtype=torch.int32)
+    index_len = torch.tensor([2, 4, 5], dtype=torch.int32)
+    cp = co.cumprod_forward(param, index)
+    torch.testing.assert_close(cp, torch.tensor([0.4, 0.08, 0.1, 0.08, 0.2]), atol=1e-7, rtol=1e-6)
+    g = co.cumprod_backward(param, cp, param.clone(), index, index_len)
+    torch.testing.assert_close(g, torch.tensor([0.44, 0.08, 0.74, 0.08, 0.2]), atol=1e-6, rtol=1e-6)
+    inv, inv_len = co.groups_from_key(index)
+    assert torch.equal(inv, index) and torch.equal(inv_len, index_len)
+
+
+def test_kat_uitility_worked_example():
+    """reference: uitility.py:383-393 — A=[1..7], groups {(1,1),(1,2),(1,1),(1,2),(1,3),(1,1),(1,3)}
+    -> [1,2,3,8,5,18,35]: grouped cumprod returned in the ORIGINAL (unsorted) order, i.e. the
+    sort -> scan -> unsort of gs_model.py:547-555."""
+    A = torch.arange(1, 8, dtype=torch.float32)
+    G = torch.tensor([[1, 1], [1, 2], [1, 1], [1, 2], [1, 3], [1, 1], [1, 3]], dtype=torch.int32)
+    T, mask, _, _ = ow.create_alpha_brend(G, A, "cumprod")
+    assert bool(mask.all())
+    # the wrapper returns inclusive/self = exclusive product; inclusive = that * A
+    torch.testing.assert_close(T * A, torch.tensor([1.0, 2.0, 3.0, 8.0, 5.0, 18.0, 35.0]))
+
+
+def _golden_cases():
+    z = np.load(os.path.join(GOLD, "scan_golden.npz"))
+    names = sorted({k.split("/")[0] for k in z.files if k.startswith("n")})
+    return z, names
+
+
+def _golden_inputs(z, name):
+    lens = torch.from_numpy(z[name + "/lens"].astype(np.int64))
+    vals = torch.from_numpy(z[name + "/vals"])
+    key = torch.repeat_interleave(vals, lens).contiguous()
+    x = ((torch.from_numpy(z[name + "/xq"].astype(np.int64)) + 1).to(torch.float32) / 65536.0).contiguous()
+    return x, key
+
+
+def test_golden_file_kat():
+    z, _ = _golden_cases()
+    np.testing.assert_allclose(z["kat/cumprod"], [0.4, 0.08, 0.1, 0.08, 0.2], rtol=1e-6)
+    np.testing.assert_allclose(z["kat/cumsum"], [0.4, 0.6, 0.1, 0.9, 0.2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", _golden_cases()[1])
+def test_oracle_bit_exact_vs_reference_golden(name):
+    """Golden outputs come from thrust::inclusive_scan_by_key (reference .cu, host backend):
+    sequential fp32, so the C oracle must reproduce them BIT FOR BIT."""
+    z, _ = _golden_cases()
+    x, key = _golden_inputs(z, name)
+    cp, cs = co.cumprod_forward(x, key), co.cumsum_forward(x, key)
+    if name.endswith("_sampled"):
+        idx = torch.from_numpy(z[name + "/idx"].astype(np.int64))
+        assert np.array_equal(cp[idx].numpy(), z[name + "/cumprod"])
+        assert np.array_equal(cs[idx].numpy(), z[name + "/cumsum"])
+        assert cp.double().sum().item() == float(z[name + "/cumprod_sum64"])
+        assert cs.double().sum().item() == float(z[name + "/cumsum_sum64"])
+    else:
+        assert np.array_equal(cp.numpy(), z[name + "/cumprod"])
+        assert np.array_equal(cs.numpy(), z[name + "/cumsum"])
+
+
+def test_oracle_vs_live_reference_host_build():
+    """Where oracle/_ref/ exists (built from /root/reference by oracle/Makefile) run the reference's
+    own forward kernels live against the C oracle on fresh inputs."""
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref_dir, "grouped_cumprod_ref_host.so")):
+        pytest.skip("oracle/_ref/grouped_cumprod_ref_host.so not built")
+    sys.path.insert(0, ref_dir)
+    import grouped_cumprod_ref_host as ref
+
+    for n, dist in [(1, "all1"), (777, "poisson8"), (50000, "geo80"), (50000, "mixed"), (9000, "one_run")]:
+        key, x = make_keys(n, dist, n), make_values(n, n)
+        y = torch.zeros_like(x)
+        ref.grouped_cumprod_forward(x, key, y)
+        assert torch.equal(y, co.cumprod_forward(x, key))
+        ref.grouped_cumsum_forward(x, key, y)
+        assert torch.equal(y, co.cumsum_forward(x, key))
+
+
+@pytest.mark.parametrize("dist", ["all1", "poisson8", "geo80", "mixed"])
+def test_torch_cumprod_path_matches_c_oracle(dist):
+    """BASELINE config 1 (256x256, ~8 splats/pixel scale): the pure-PyTorch torch.cumprod path and the
+    C restatement agree to fp32 rounding (torch.cumprod is also a left-to-right product)."""
+    n = 65536 * 8 if dist == "poisson8" else 60000
+    key, x = make_keys(n, dist, 3), make_values(n, 3)
+    torch.testing.assert_close(tp.grouped_cumprod(x, key), co.cumprod_forward(x, key), atol=1e-6, rtol=1e-5)
+    xs = make_values(n, 4, "normal")
+    want = co.cumsum_forward(xs, key)
+    scale = co.cumsum_forward_f64(xs.abs(), key)
+    assert bool(((tp.grouped_cumsum(xs, key).double() - want.double()).abs() <= 1e-5 * (1 + scale)).all())
+
+
+def test_backward_is_the_vjp_of_cumprod():
+    """For non-zero params the reference kernel (grouped_cumprod_backward.cu:22-29) is the true VJP:
+    compare the literal restatement with torch autograd through per-group torch.cumprod, and with
+    the O(n) fp64 form."""
+    n = 4000
+    key, x = make_keys(n, "poisson8", 9), make_values(n, 9)
+    inv, inv_len = co.groups_from_key(key)
+    go = make_values(n, 10, "normal")
+    cp = co.cumprod_forward(x, key)
+    lit = co.cumprod_backward(x, cp, go, inv, inv_len)
+    auto = tp.grouped_cumprod_backward_autograd(x, key, go)
+    f64 = co.cumprod_backward_f64(x, cp, go, inv)
+    scale = co.cumprod_backward_f64(x, cp, go.abs(), inv)
+    assert bool(((lit.double() - f64).abs() <= 1e-5 * (1 + scale)).all())
+    assert bool(((auto.double() - f64).abs() <= 1e-5 * (1 + scale)).all())
+
+
+def test_backward_zero_param_rule():
+    """grouped_cumprod_backward.cu:25: a zero param is replaced by 1e-8 in the divisor."""
+    x = torch.tensor([0.5, 0.0, 0.25])
+    key = torch.zeros(3, dtype=torch.int32)
+    inv, inv_len = co.groups_from_key(key)
+    cp = co.cumprod_forward(x, key)  # [0.5, 0, 0]
+    go = torch.tensor([1.0, 1.0, 1.0])
+    g = co.cumprod_backward(x, cp, go, inv, inv_len)
+    torch.testing.assert_close(g, torch.tensor([1.0, 0.0, 0.0]))
+
+
+def test_wrappers_vs_reference_function_golden():
+    """a5/a6: the restated wrappers reproduce what the reference's own `_create_alpha_brend` and
+    `grad_cumsum` returned (tests/golden/function_golden.npz), indices bit-exact."""
+    z = np.load(os.path.join(GOLD, "function_golden.npz"))
+    for name in ("wrap_small", "wrap_mid"):
+        rects = torch.from_numpy(z[name + "/rects"])
+        anti = torch.from_numpy(z[name + "/anti_opacity"])
+        T, mask, sorted_inv, index = ow.create_alpha_brend(rects, anti, "cumprod")
+        assert np.array_equal(sorted_inv.numpy(), z[name + "/sorted_inv"])
+        assert np.array_equal(index.numpy(), z[name + "/index"])
+        assert np.array_equal(mask.numpy(), z[name + "/T_mask"])
+        assert np.array_equal(T.numpy(), z[name + "/T"])
+        grad = torch.from_numpy(z[name + "/grad"])
+        S, smask = ow.grad_cumsum(rects, grad)
+        assert np.array_equal(smask.numpy(), z[name + "/S_mask_flipped"])
+        assert np.array_equal(S.numpy(), z[name + "/S"])
+
+
+def test_empty_inputs():
+    e, k = torch.zeros(0), torch.zeros(0, dtype=torch.int32)
+    assert co.cumprod_forward(e, k).numel() == 0
+    assert co.cumsum_forward(e, k).numel() == 0
+    assert co.cumprod_backward(e, e, e, k, k).numel() == 0
+    assert tp.grouped_cumprod(e, k).numel() == 0

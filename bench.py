@@ -158,6 +158,33 @@ def main():
     else:
         total_pairs = float(m)
 
+    # frame assembly / gradient distribution (outside the timed region; the scan path has no collective)
+    gather_ms = scatter_ms = None
+    if world > 1:
+        try:
+            from simplegaussiansplat_tk71_amd import sharding
+
+            counts = torch.tensor([p.n_groups, m], dtype=torch.int64, device=dev)
+            allc = [torch.empty_like(counts) for _ in range(world)]
+            dist.all_gather(allc, counts)
+            shards = sharding.shards_from_counts([int(c[0]) for c in allc], [int(c[1]) for c in allc])
+            rows = torch.rand(p.n_groups, 3, device=dev)
+            for it in range(3):
+                sync()
+                t1 = time.perf_counter()
+                full = sharding.gather_groups(rows, shards, dst=0)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                back = sharding.scatter_groups(full, shards, like=rows, src=0)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+            assert torch.equal(back, rows)
+            tt = torch.tensor([t2 - t1, t3 - t2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            gather_ms, scatter_ms = float(tt[0]) * 1e3, float(tt[1]) * 1e3
+        except Exception as e:  # never let the optional collective timing break the headline number
+            print(f"[rank {rank}] gather/scatter timing skipped: {e!r}", file=sys.stderr)
+
     if rank == 0:
         ach = BYTES_BWD * m / t_bwd / 1e9
         out = {
@@ -181,6 +208,8 @@ def main():
                 "bytes_per_pair": BYTES_FWD + BYTES_BWD,
                 "aggregate_algorithmic_GBps": (BYTES_FWD + BYTES_BWD) * total_pairs * args.steps / elapsed / 1e9,
                 "fallback_tiles_last_launch": fallback,
+                "frame_gather_ms": gather_ms,
+                "grad_scatter_ms": scatter_ms,
             },
             "roofline": {
                 "kernel": "gcp_scan_main<CUMPROD_BWD> (grouped_cumprod_backward)",

@@ -1,0 +1,139 @@
+"""Pixel-group sharding of the pair list across the GPUs of one node.
+
+The reference is single-GPU (no communication backend); this is the MI355X-native
+addition of SURVEY.md §8(e).  Pixel groups (runs of equal key = one pixel's depth-sorted splats) are
+independent, so the scans need NO collective: the pair list is cut at group boundaries and every
+rank scans its slice.  Only frame assembly (per-group results -> one image on the loss rank) and
+its backward (dL/dI -> owning ranks) move data: ONE gather and ONE scatter of per-group rows.
+
+One process per GPU, `torch.distributed`; backend "nccl" is RCCL on ROCm.  A gather/scatter to one
+root over the xGMI full mesh uses the 7 point-to-point links into the root concurrently (≈153 GB/s
+each), so it is bound by the per-link size of ONE rank's band, not by a ring: at 4K (99.5 MB frame,
+8 ranks) ≈12.4 MB per link ≈ 81 µs.  Works unchanged on CPU tensors with backend "gloo" (tests).
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    group_start: int  # first pixel group owned
+    group_end: int    # one past the last
+    pair_start: int   # first pair owned (a group boundary)
+    pair_end: int
+
+    @property
+    def n_groups(self):
+        return self.group_end - self.group_start
+
+    @property
+    def n_pairs(self):
+        return self.pair_end - self.pair_start
+
+
+def partition_groups(inv_len: torch.Tensor, world_size: int) -> List[Shard]:
+    """Cut [0, M) into `world_size` contiguous slices at the group boundaries nearest k*M/R
+    (balance by pairs, not by pixels or rows).  `inv_len` = exclusive end offset per group
+    (the reference's convention, cuda_test.py:27).  Pure index arithmetic: identical on every rank."""
+    g = inv_len.numel()
+    ends = inv_len.detach().to("cpu", torch.int64)
+    m = int(ends[-1].item()) if g else 0
+    cuts = [0]
+    for k in range(1, world_size):
+        target = (m * k) // world_size
+        # group boundary nearest to target: boundaries are 0 and ends[i]
+        i = int(torch.searchsorted(ends, torch.tensor(target, dtype=torch.int64), right=False).item())
+        i = min(i, g - 1) if g else 0
+        hi = int(ends[i].item()) if g else 0
+        lo = int(ends[i - 1].item()) if i > 0 else 0
+        cut_groups = i + 1 if (hi - target) <= (target - lo) else i
+        cuts.append(max(cuts[-1], min(cut_groups, g)))
+    cuts.append(g)
+    shards = []
+    for r in range(world_size):
+        g0, g1 = cuts[r], cuts[r + 1]
+        p0 = int(ends[g0 - 1].item()) if g0 > 0 else 0
+        p1 = int(ends[g1 - 1].item()) if g1 > 0 else 0
+        shards.append(Shard(r, g0, g1, p0, p1))
+    return shards
+
+
+def shards_from_counts(group_counts: Sequence[int], pair_counts: Sequence[int]) -> List[Shard]:
+    """Shard table for ranks that already own disjoint bands (e.g. one image band generated per rank)."""
+    out, g, p = [], 0, 0
+    for r, (gc, pc) in enumerate(zip(group_counts, pair_counts)):
+        out.append(Shard(r, g, g + int(gc), p, p + int(pc)))
+        g += int(gc)
+        p += int(pc)
+    return out
+
+
+def local_arrays(shard: Shard, key, x, inv, inv_len, *more):
+    """This rank's slice of the flat arrays, with group ids and end offsets rebased to the slice
+    (contiguous views: no copy).  Extra per-pair arrays in `more` are sliced alike."""
+    p = slice(shard.pair_start, shard.pair_end)
+    g = slice(shard.group_start, shard.group_end)
+    out = [key[p], x[p], inv[p] - shard.group_start, inv_len[g] - shard.pair_start]
+    out += [t[p] for t in more]
+    return out
+
+
+def _padded(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.size(0) == rows:
+        return t.contiguous()
+    out = t.new_zeros((rows,) + tuple(t.shape[1:]))
+    out[: t.size(0)] = t
+    return out
+
+
+def gather_groups(local: torch.Tensor, shards: Sequence[Shard], dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """ONE gather of per-group rows (e.g. pixel colours [G_r, 3]) to `dst`; returns the
+    concatenation [G, ...] there and None elsewhere.  Bands differ in group count, so rows are
+    padded to the largest band for the collective and trimmed after."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(shards) == world and local.size(0) == shards[rank].n_groups
+    rows = max(s.n_groups for s in shards)
+    send = _padded(local, rows)
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return torch.cat([b[: s.n_groups] for b, s in zip(bufs, shards)], 0)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def scatter_groups(full: Optional[torch.Tensor], shards: Sequence[Shard], like: torch.Tensor, src: int = 0, group=None):
+    """ONE scatter of per-group rows from `src` (e.g. dL/dI rows of the loss rank) to their owners.
+    `like` gives dtype/device/trailing shape on the receiving ranks."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = max(s.n_groups for s in shards)
+    recv = like.new_empty((rows,) + tuple(like.shape[1:]))
+    if rank == src:
+        assert full is not None and full.size(0) == shards[-1].group_end
+        parts = [_padded(full[s.group_start : s.group_end], rows) for s in shards]
+        dist.scatter(recv, parts, src=src, group=group)
+    else:
+        dist.scatter(recv, None, src=src, group=group)
+    return recv[: shards[rank].n_groups]
+
+
+def frame_from_groups(values: torch.Tensor, group_key: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """Per-group rows -> image in the reference's (H+1, W+1, C) layout (gs_model.py:505), pixel
+    key = y*10000 + x (gs_model.py:538-541).  Groups are unique pixels, so this is a plain
+    scatter: no atomics (the reference accumulates per pair with index_put_(accumulate=True), :510-514)."""
+    img = values.new_zeros((height + 1, width + 1) + tuple(values.shape[1:]))
+    k = group_key.long()
+    img[k // 10000, k % 10000] = values
+    return img
+
+
+def groups_from_frame(frame: torch.Tensor, group_key: torch.Tensor) -> torch.Tensor:
+    """Inverse gather: dL/dI at every group's pixel (gs_model.py:703-706)."""
+    k = group_key.long()
+    return frame[k // 10000, k % 10000]

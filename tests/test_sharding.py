@@ -1,0 +1,113 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes.  Each rank scans ITS slice (with the oracle —
+this is a test) and one gather / one scatter move per-group rows; results must equal the unsharded
+computation exactly (groups are independent, so sharding changes no arithmetic)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from simplegaussiansplat_tk71_amd import sharding, synthetic
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_partition_is_balanced_and_on_group_boundaries():
+    p = synthetic.make_pairs(64, 96, 20.0, deep=True, seed=5)
+    for world in (1, 2, 3, 8):
+        shards = sharding.partition_groups(p.inv_len, world)
+        assert len(shards) == world
+        assert shards[0].pair_start == 0 and shards[-1].pair_end == p.n_pairs
+        assert shards[0].group_start == 0 and shards[-1].group_end == p.n_groups
+        for a, b in zip(shards, shards[1:]):
+            assert a.pair_end == b.pair_start and a.group_end == b.group_start
+        for s in shards:
+            if s.n_groups:
+                assert s.pair_end == int(p.inv_len[s.group_end - 1])
+                assert s.pair_start == (int(p.inv_len[s.group_start - 1]) if s.group_start else 0)
+            # balance: no slice is off its share by more than the longest group
+            assert abs(s.n_pairs - p.n_pairs / world) <= int(p.run_len.max()) + 1
+            key, x, inv, inv_len = sharding.local_arrays(s, p.key, p.x, p.inv, p.inv_len)
+            assert key.numel() == s.n_pairs
+            if s.n_groups:
+                assert int(inv.min()) == 0 and int(inv.max()) == s.n_groups - 1 and int(inv_len[-1]) == s.n_pairs
+
+
+def test_partition_degenerate():
+    one = torch.tensor([10], dtype=torch.int32)
+    shards = sharding.partition_groups(one, 4)
+    assert sum(s.n_groups for s in shards) == 1 and sum(s.n_pairs for s in shards) == 10
+    empty = sharding.partition_groups(torch.zeros(0, dtype=torch.int32), 2)
+    assert all(s.n_pairs == 0 and s.n_groups == 0 for s in empty)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle as co
+
+        h, w = 40, 64
+        p = synthetic.make_pairs(h, w, 16.0, deep=True, seed=9)
+        colour = torch.rand(p.n_pairs, 3, generator=torch.Generator().manual_seed(1))
+        shards = sharding.partition_groups(p.inv_len, world)
+        s = shards[rank]
+        key, x, inv, inv_len, col = sharding.local_arrays(s, p.key, p.x, p.inv, p.inv_len, colour)
+        # forward on this rank's slice only: transmittance, then per-pixel colour sum
+        cp = co.cumprod_forward(x.contiguous(), key.contiguous())
+        T = cp / x  # exclusive (gs_model.py:562)
+        pix = torch.zeros(s.n_groups, 3).index_add_(0, inv.long(), T[:, None] * col)
+        group_key = torch.unique_consecutive(p.key)
+        frame_rows = sharding.gather_groups(pix, shards, dst=0)
+        # backward: rank 0 owns dL/dI, scatters the rows of every band to its owner
+        gI = torch.randn(h + 1, w + 1, 3, generator=torch.Generator().manual_seed(2))
+        full_rows = sharding.groups_from_frame(gI, group_key) if rank == 0 else None
+        my_rows = sharding.scatter_groups(full_rows, shards, like=pix, src=0)
+        pair_grad = (my_rows[inv.long()] * (T[:, None] * col)).sum(1)  # (g . p) per pair, gs_model.py:632
+        suffix = co.cumsum_reverse(pair_grad.contiguous(), key.contiguous())
+        local = {"suffix": suffix, "rows": my_rows}
+        if rank == 0:
+            # unsharded reference computation
+            cp_all = co.cumprod_forward(p.x, p.key)
+            T_all = cp_all / p.x
+            pix_all = torch.zeros(p.n_groups, 3).index_add_(0, p.inv.long(), T_all[:, None] * colour)
+            assert torch.equal(frame_rows, pix_all)
+            frame = sharding.frame_from_groups(frame_rows, group_key, h, w)
+            assert frame.shape == (h + 1, w + 1, 3)
+            assert torch.equal(sharding.groups_from_frame(frame, group_key), pix_all)
+            rows_all = sharding.groups_from_frame(gI, group_key)
+            pg_all = (rows_all[p.inv.long()] * (T_all[:, None] * colour)).sum(1)
+            suffix_all = co.cumsum_reverse(pg_all, p.key)
+            local["suffix_all"] = suffix_all
+            local["rows_all"] = rows_all
+        q.put((rank, s.pair_start, s.pair_end, s.group_start, s.group_end, {k: v.clone() for k, v in local.items()}))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_forward_gather_backward_scatter():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    ref = got[0][5]
+    for rank, p0, p1, g0, g1, loc in got:
+        assert torch.equal(loc["suffix"], ref["suffix_all"][p0:p1])
+        assert torch.equal(loc["rows"], ref["rows_all"][g0:g1])

@@ -130,6 +130,78 @@ int gcp_tile_elems(void);
  * (synchronises `stream`; ws == NULL selects the internal workspace). */
 int gcp_last_fallback_tiles(void* ws, void* stream, int64_t* n_tiles);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Rows f1 / f2 of SURVEY.md §8: everything the reference's autograd Function does AROUND its
+ * scan (reference: gs_model.py:598-663 _forward_batch/_backward_batch, :666-692 forward,
+ * :786-820 backward), restated tile-based so that no splat-pixel pair array is ever
+ * materialised.  Gaussians are given in depth order (front to back = array order) with integer
+ * INCLUSIVE pixel boxes start_xy/end_xy int32[N,2] (x,y) (uitility.py:336-366), float means
+ * [N,2], precision matrices vinv f32[N,2,2], opacity f32[N], colour l_d f32[N,3].  Images are
+ * f32[(H+1),(W+1),3] (gs_model.py:505).  Tiles are 16x16 pixels.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Tile grid of a (height+1) x (width+1) image. */
+int gcp_tile_grid(int32_t width, int32_t height, int32_t* tiles_x, int32_t* tiles_y);
+
+/* Exclusive prefix sum of int32; out has n+1 entries (out[n] = total). */
+size_t gcp_scan_i32_workspace_bytes(int64_t n);
+int gcp_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* f2, step 1: tile_off[g] = exclusive prefix of the number of tiles box g touches
+ * (tile_off has n_gauss+1 entries).  Synchronises `stream` once to return the total K on the
+ * host (the reference synchronises likewise: uitility.py:348 `.item()`).
+ * ws: gcp_bin_workspace_bytes(n_gauss, 0) bytes. */
+int gcp_bin_tiles_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
+                        int32_t width, int32_t height, int32_t* tile_off,
+                        int64_t* n_tile_pairs_host, void* ws, size_t ws_bytes, void* stream);
+size_t gcp_bin_workspace_bytes(int64_t n_gauss, int64_t n_tile_pairs);
+/* f2, step 2: tile_list[K] = Gaussian ids grouped by tile, depth order inside each tile (stable
+ * radix sort of the Gaussian-major (tile, gaussian) entries); tile_start[n_tiles+1] = first entry
+ * of every tile.  Replaces torch.sort / argsort / unique over M pixel keys
+ * (gs_model.py:546-555, :582-586). */
+int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
+                       int32_t width, int32_t height, const int32_t* tile_off,
+                       int64_t n_tile_pairs, int32_t* tile_start, int32_t* tile_list, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* f1 forward: image = sum over pairs of T * l * o * g with T the exclusive grouped cumprod of
+ * (1 - o g) per pixel in depth order; pairs whose inclusive product is exactly 0 are dropped.
+ * Replaces _forward_batch + index_put_(accumulate=True) (gs_model.py:598-624, :510-514). */
+int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
+                      const float* vinv, const float* opacity, const float* l_d, int64_t n_gauss,
+                      int32_t width, int32_t height, const int32_t* tile_start,
+                      const int32_t* tile_list, float* image, void* stream);
+
+/* f1 backward: gradients of <image, grad_image> w.r.t. mean [N,2], vinv [N,2,2], opacity [N],
+ * l_d [N,3].  `image` is the forward result.  Replaces _backward_batch + grad_list_to_gause
+ * (gs_model.py:627-663, :733-783).  grad_l is the TRUE gradient (the reference's is
+ * channel-collapsed, gs_model.py:710-712,:763-766).  ws: gcp_blend_backward_workspace_bytes(K). */
+size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs);
+int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
+                       const float* vinv, const float* opacity, const float* l_d, int64_t n_gauss,
+                       int32_t width, int32_t height, const int32_t* tile_off,
+                       int64_t n_tile_pairs, const int32_t* tile_start, const int32_t* tile_list,
+                       const float* image, const float* grad_image, float* grad_mean,
+                       float* grad_vinv, float* grad_opacity, float* grad_l, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* f2, CSR export for callers of the scan API: per-pixel pair counts (row-major over the
+ * (H+1)x(W+1) image = ascending pixel key y*10000+x) and box sizes; then, given their exclusive
+ * prefix sums, pair_gauss[M] (Gaussian of every pair, pixel-major, depth order) and
+ * pair_index[M] (the pair's position in the reference's Gaussian-major rect list) — i.e. the
+ * `index` torch.sort(stable) returns at gs_model.py:547, bit for bit. */
+int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
+                          int32_t width, int32_t height, const int32_t* tile_start,
+                          const int32_t* tile_list, int32_t* pixel_count, int32_t* box_size,
+                          void* stream);
+int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
+                         int32_t width, int32_t height, const int32_t* tile_start,
+                         const int32_t* tile_list, const int32_t* pixel_off,
+                         const int32_t* box_off, int32_t* pair_gauss, int32_t* pair_index,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

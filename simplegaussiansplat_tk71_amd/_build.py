@@ -11,7 +11,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-SRC = os.path.join(PKG_DIR, "csrc", "gcp_scan.hip")
+SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("gcp_scan.hip", "gcp_raster.hip")]
+HDRS = [os.path.join(PKG_DIR, "csrc", "gcp_device.hpp")]
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgrouped_cumprod_hip.so")
@@ -37,7 +38,7 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, os.path.join(INCLUDE, "grouped_cumprod_hip.h"), os.path.abspath(__file__)]
+    deps = [*SRCS, *HDRS, os.path.join(INCLUDE, "grouped_cumprod_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -46,7 +47,7 @@ def build_hip_library(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc(), *HIPCC_FLAGS, *extra_flags, "-I", INCLUDE, "-o", LIB_PATH, SRC]
+    cmd = [find_hipcc(), *HIPCC_FLAGS, *extra_flags, "-I", INCLUDE, "-o", LIB_PATH, *SRCS]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

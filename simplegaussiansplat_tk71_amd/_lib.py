@@ -12,6 +12,7 @@ from ._build import LIB_PATH
 _c_void_p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _sz = ctypes.c_size_t
+_i32 = ctypes.c_int32
 
 # name -> (restype, argtypes); must list every symbol include/grouped_cumprod_hip.h declares
 SIGNATURES = {
@@ -30,6 +31,30 @@ SIGNATURES = {
     "gcp_check_groups": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, ctypes.POINTER(_i64), _c_void_p]),
     "gcp_tile_elems": (ctypes.c_int, []),
     "gcp_last_fallback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
+    # rows f1 / f2 (gcp_raster.hip)
+    "gcp_tile_grid": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "gcp_scan_i32_workspace_bytes": (_sz, [_i64]),
+    "gcp_exclusive_scan_i32": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_bin_tiles_count": (
+        ctypes.c_int,
+        [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, ctypes.POINTER(_i64), _c_void_p, _sz, _c_void_p],
+    ),
+    "gcp_bin_workspace_bytes": (_sz, [_i64, _i64]),
+    "gcp_bin_tiles_fill": (
+        ctypes.c_int,
+        [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p],
+    ),
+    "gcp_blend_forward": (
+        ctypes.c_int,
+        [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    ),
+    "gcp_blend_backward_workspace_bytes": (_sz, [_i64]),
+    "gcp_blend_backward": (
+        ctypes.c_int,
+        [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p, _i64] + [_c_void_p] * 8 + [_c_void_p, _sz, _c_void_p],
+    ),
+    "gcp_pixel_lists_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5),
+    "gcp_pixel_lists_fill": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 7),
 }
 
 ABI_VERSION = 1

@@ -1,0 +1,670 @@
+// gcp_raster.hip — tile binning and fused per-pixel alpha blending.
+//
+// What the reference does around its scan (reference: gs_model.py:598-663, :666-692, :786-820):
+// expand every Gaussian's box into M splat-pixel pairs, compute the Gaussian kernel per pair,
+// radix-sort the M pixel keys, scan, un-sort (second radix sort), compact, blend, scatter-add
+// into the image with atomics — ~20 passes over M-length arrays — and the same again (recomputed)
+// in backward, plus a pair->Gaussian scatter_reduce.
+//
+// MI355X-first restatement, same results, no M-length array at all:
+//   f2  Bin Gaussians (given in depth order) into 16x16-pixel tiles: count tiles per box, prefix
+//       sum, emit (tile, gaussian) entries Gaussian-major, STABLE LSD radix sort on the tile id
+//       (8-bit digits; ranks from wave ballots, one wave per block => deterministic), so every
+//       tile's list is in depth order.  K entries (~3 per Gaussian) instead of M pairs (~166).
+//   f1  One 256-thread block per tile, one pixel per lane.  The tile's list is staged through LDS
+//       256 entries at a time; every lane walks it in depth order keeping its own transmittance
+//       T (the exclusive grouped cumprod of the scan path, sequential per pixel), box-tests,
+//       evaluates g = exp(-0.5 d Λ d^T), and accumulates colour.  Pixels are owned by lanes:
+//       no atomics, deterministic.  A wave skips an entry when no lane is inside its box.
+//       Backward walks FORWARD too: the exclusive suffix sum of (dL/dI . p) the reference gets
+//       from a flipped grouped cumsum (gs_model.py:716-722) equals (dL/dI . I) - inclusive
+//       prefix, and I is the saved forward image.  Per-pair gradients are summed over the
+//       tile's pixels by DPP wave reductions into one slot per (tile, Gaussian) entry
+//       (Gaussian-major order), and a last kernel sums each Gaussian's few slots.
+//       No float atomics anywhere => bitwise reproducible.
+//   The per-pixel CSR (pixel offsets, pair->Gaussian, pair->rect index) that the scan API
+//   consumes is exported by the same traversal (k_pixel_count / k_pixel_fill): bit-exact with
+//   torch.sort(stable=True) of the reference's pixel keys (gs_model.py:546-547).
+//
+// Reference semantics kept: integer inclusive boxes (uitility.py:336-366), depth order = input
+// order, pair dropped when its INCLUSIVE product is exactly 0 (gs_model.py:560,:575-578),
+// image layout (H+1, W+1, 3) (gs_model.py:505), single chunk.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gcp_device.hpp"
+#include "grouped_cumprod_hip.h"
+
+namespace {
+using namespace gcp;
+
+constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
+constexpr int kStage = 256;         // list entries staged per LDS round (forward)
+constexpr int kStageBwd = 128;      // (backward; LDS also holds the per-wave partial sums)
+constexpr int kGradVals = 9;        // go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
+constexpr int kGradStride = 12;     // floats per partial slot in LDS (16-byte aligned)
+constexpr int kSortChunk = 2048;    // keys per radix block
+constexpr int kScanChunk = 2048;    // ints per prefix-sum block
+
+struct TileGrid { int tx, ty; };
+inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTile - 1) / kTile, (H + 1 + kTile - 1) / kTile}; }
+
+// ------------------------------------------------------------------------------------------
+// Exclusive prefix sum of int32 (out has n+1 entries, out[n] = total).  Three small launches.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan_256(int v, int* s_w, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int inc = wave_incl_scan_i(v);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int t = s_w[j]; if (j < w) woff += t; tot += t; }
+  total = tot;
+  __syncthreads();
+  return woff + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const int* in, int* bsum, i64 n) {
+  __shared__ int s_w[4];
+  const i64 base = (i64)blockIdx.x * kScanChunk + (i64)threadIdx.x * 8;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (base + k < n) s += in[base + k];
+  int total;
+  block_excl_scan_256(s, s_w, total);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_bsums(int* bsum, i64 nb, int* total_out) {
+  __shared__ int s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int carry = 0;
+  for (i64 base = 0; base < nb; base += 1024) {
+    const i64 i = base + tid;
+    const int v = (i < nb) ? bsum[i] : 0;
+    const int inc = wave_incl_scan_i(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int j = 0; j < 16; ++j) { const int t = s_w[j]; if (j < w) woff += t; tot += t; }
+    if (i < nb) bsum[i] = carry + woff + inc - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int* in, const int* boff, int* out, i64 n) {
+  __shared__ int s_w[4];
+  const i64 base = (i64)blockIdx.x * kScanChunk + (i64)threadIdx.x * 8;
+  int v[8];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  int total;
+  int ex = block_excl_scan_256(s, s_w, total) + boff[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+}
+
+// host: ws needs ceil(n/2048) ints
+int launch_excl_scan(const int* in, int* out, i64 n, int* ws, hipStream_t stream) {
+  if (n <= 0) {
+    GCP_HIP(hipMemsetAsync(out, 0, sizeof(int), stream));
+    return GCP_OK;
+  }
+  const i64 nb = (n + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, stream, in, ws, n);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, stream, ws, nb, out + n);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, in, (const int*)ws, out, n);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// f2: tile binning
+// ------------------------------------------------------------------------------------------
+struct Box { int x0, y0, x1, y1; };
+__device__ __forceinline__ bool load_box(const int* start, const int* end, i64 g, int W, int H, Box& b) {
+  b.x0 = max(start[2 * g], 0);
+  b.y0 = max(start[2 * g + 1], 0);
+  b.x1 = min(end[2 * g], W);
+  b.y1 = min(end[2 * g + 1], H);
+  return b.x1 >= b.x0 && b.y1 >= b.y0;
+}
+
+__global__ void k_tile_count(const int* start, const int* end, i64 n, int W, int H, int* cnt) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Box b;
+  int c = 0;
+  if (load_box(start, end, g, W, H, b))
+    c = ((b.x1 >> 4) - (b.x0 >> 4) + 1) * ((b.y1 >> 4) - (b.y0 >> 4) + 1);
+  cnt[g] = c;
+}
+
+__global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
+                            const int* off, unsigned* key, unsigned* val) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Box b;
+  if (!load_box(start, end, g, W, H, b)) return;
+  int e = off[g];
+  for (int ty = b.y0 >> 4; ty <= (b.y1 >> 4); ++ty)
+    for (int tx = b.x0 >> 4; tx <= (b.x1 >> 4); ++tx) {
+      key[e] = (unsigned)(ty * tiles_x + tx);
+      val[e] = (unsigned)g;
+      ++e;
+    }
+}
+
+// stable LSD radix sort, 8-bit digit.  hist layout [digit][block] so one linear exclusive scan
+// yields, for every (digit, block), the first output slot of that block's keys of that digit.
+__global__ __launch_bounds__(256) void k_radix_hist(const unsigned* key, i64 K, int shift, int* hist, int nblk) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const i64 base = (i64)blockIdx.x * kSortChunk;
+  for (int i = threadIdx.x; i < kSortChunk; i += 256)
+    if (base + i < K) atomicAdd(&h[(key[base + i] >> shift) & 255u], 1);
+  __syncthreads();
+  hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_radix_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
+                                                       unsigned* val_out, i64 K, int shift, const int* hist_excl,
+                                                       int nblk) {
+  __shared__ int off[256];
+  const int lane = threadIdx.x;
+  for (int d = lane; d < 256; d += 64) off[d] = hist_excl[(i64)d * nblk + blockIdx.x];
+  __syncthreads();
+  const i64 base = (i64)blockIdx.x * kSortChunk;
+  for (int step = 0; step < kSortChunk / 64; ++step) {
+    const i64 i = base + step * 64 + lane;
+    const bool valid = i < K;
+    const unsigned k = valid ? key[i] : 0u;
+    const unsigned v = valid ? val[i] : 0u;
+    const unsigned d = (k >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));  // earlier lanes first: stable
+    const int pos = off[d];
+    __syncthreads();
+    if (valid && rank == 0) off[d] = pos + __builtin_popcountll(peers);
+    __syncthreads();
+    if (valid) {
+      key_out[pos + rank] = k;
+      val_out[pos + rank] = v;
+    }
+  }
+}
+
+// tile_start[t] = first sorted entry whose tile id is >= t, for t in [0, n_tiles]
+__global__ void k_tile_bounds(const unsigned* key, i64 K, int n_tiles, int* tile_start) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > K) return;
+  const int prev = (i == 0) ? -1 : (int)key[i - 1];
+  const int cur = (i == K) ? n_tiles : (int)key[i];
+  for (int t = prev + 1; t <= cur; ++t) tile_start[t] = (int)i;
+}
+
+// ------------------------------------------------------------------------------------------
+// f1: fused blend
+// ------------------------------------------------------------------------------------------
+struct BlendArgs {
+  const int* start;      // [N,2] x,y inclusive
+  const int* end;        // [N,2]
+  const float* mean;     // [N,2] x,y
+  const float* vinv;     // [N,2,2]
+  const float* opacity;  // [N]
+  const float* l_d;      // [N,3]
+  const int* tile_start; // [n_tiles+1]
+  const unsigned* tile_list;  // [K] gaussian id, depth order inside each tile
+  int W, H, tiles_x;
+};
+
+template <int STAGE>
+struct Staged {
+  int4 box[STAGE];
+  float4 geo[STAGE];   // mx, my, opacity, -
+  float4 vin[STAGE];   // a b c d  (Λ = [[a,b],[c,d]])
+  float4 col[STAGE];   // l0 l1 l2 -
+};
+
+template <int STAGE>
+__device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>& s, int first, int cnt) {
+  for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+    const i64 g = a.tile_list[first + j];
+    Box b;
+    load_box(a.start, a.end, g, a.W, a.H, b);
+    s.box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
+    s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], a.opacity[g], 0.0f);
+    s.vin[j] = make_float4(a.vinv[4 * g], a.vinv[4 * g + 1], a.vinv[4 * g + 2], a.vinv[4 * g + 3]);
+    s.col[j] = make_float4(a.l_d[3 * g], a.l_d[3 * g + 1], a.l_d[3 * g + 2], 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __restrict__ image) {
+  __shared__ Staged<kStage> s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int px = (tile % a.tiles_x) * kTile + (lane & 15);
+  const int py = (tile / a.tiles_x) * kTile + w * 4 + (lane >> 4);
+  const float fx = (float)px, fy = (float)py;
+  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+  for (int base = first; base < last; base += kStage) {
+    const int cnt = min(kStage, last - base);
+    __syncthreads();
+    stage_entries<kStage>(a, s, base, cnt);
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const int4 bx = s.box[k];
+      const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+      if (__ballot(in) == 0ull) continue;
+      if (in) {
+        const float4 ge = s.geo[k];
+        const float4 vi = s.vin[k];
+        const float4 co = s.col[k];
+        const float dx = fx - ge.x, dy = fy - ge.y;
+        // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
+        const float t0 = dx * vi.x + dy * vi.z;
+        const float t1 = dx * vi.y + dy * vi.w;
+        const float g = expf(-0.5f * (t0 * dx + t1 * dy));
+        const float anti = 1.0f - ge.z * g;             // gs_model.py:535
+        const float incl = T * anti;                    // inclusive grouped cumprod
+        if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
+          const float wgt = T * ge.z * g;               // gs_model.py:500
+          c0 += wgt * co.x; c1 += wgt * co.y; c2 += wgt * co.z;
+        }
+        T = incl;
+      }
+    }
+  }
+  if (px <= a.W && py <= a.H) {
+    float* o = image + ((i64)py * (a.W + 1) + px) * 3;
+    o[0] = c0; o[1] = c1; o[2] = c2;
+  }
+}
+
+// Backward: per (tile, entry) partial sums, written to the entry's Gaussian-major slot.
+__global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int* __restrict__ tile_off,
+                                                   const float* __restrict__ image,
+                                                   const float* __restrict__ grad_image,
+                                                   float* __restrict__ partial /*[K][kGradVals]*/) {
+  __shared__ Staged<kStageBwd> s;
+  __shared__ __attribute__((aligned(16))) float s_part[kStageBwd][4][kGradStride];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int ttx = tile % a.tiles_x, tty = tile / a.tiles_x;
+  const int px = ttx * kTile + (lane & 15);
+  const int py = tty * kTile + w * 4 + (lane >> 4);
+  const float fx = (float)px, fy = (float)py;
+  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, gC = 0.0f;
+  if (px <= a.W && py <= a.H) {
+    const i64 o = ((i64)py * (a.W + 1) + px) * 3;
+    g0 = grad_image[o]; g1 = grad_image[o + 1]; g2 = grad_image[o + 2];
+    gC = g0 * image[o] + g1 * image[o + 1] + g2 * image[o + 2];  // sum over the pixel's pairs of (g . p)
+  }
+  float T = 1.0f, acc = 0.0f;
+  for (int base = first; base < last; base += kStageBwd) {
+    const int cnt = min(kStageBwd, last - base);
+    __syncthreads();
+    stage_entries<kStageBwd>(a, s, base, cnt);
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const int4 bx = s.box[k];
+      const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+      if (__ballot(in) == 0ull) {
+        if (lane < kGradStride) s_part[k][w][lane] = 0.0f;
+        continue;
+      }
+      float r_o = 0.0f, r_l0 = 0.0f, r_l1 = 0.0f, r_l2 = 0.0f, r_cx = 0.0f, r_cy = 0.0f, r_xx = 0.0f, r_xy = 0.0f,
+            r_yy = 0.0f;
+      if (in) {
+        const float4 ge = s.geo[k];
+        const float4 vi = s.vin[k];
+        const float4 co = s.col[k];
+        const float dx = fx - ge.x, dy = fy - ge.y;
+        const float t0 = dx * vi.x + dy * vi.z;
+        const float t1 = dx * vi.y + dy * vi.w;
+        const float g = expf(-0.5f * (t0 * dx + t1 * dy));
+        const float op = ge.z;
+        const float anti = 1.0f - op * g;
+        const float incl = T * anti;
+        if (incl != 0.0f) {
+          const float wgt = T * op * g;
+          const float gp = g0 * (wgt * co.x) + g1 * (wgt * co.y) + g2 * (wgt * co.z);  // gs_model.py:632
+          acc += gp;
+          const float S = gC - acc;                 // exclusive suffix sum of gp (gs_model.py:716-722)
+          const float sa = S / anti;
+          r_o = -(g * sa) + (op != 0.0f ? gp / op : 0.0f);          // gs_model.py:733-740
+          r_l0 = g0 * wgt; r_l1 = g1 * wgt; r_l2 = g2 * wgt;        // true dL/dl (reference: gp / l, Q2)
+          const float common = gp - (op * g) * sa;                  // gs_model.py:747-748, :757-758
+          r_cx = common * dx; r_cy = common * dy;
+          r_xx = common * dx * dx; r_xy = common * dx * dy; r_yy = common * dy * dy;
+        }
+        T = incl;
+      }
+      r_o = wave_sum_f(r_o);
+      r_l0 = wave_sum_f(r_l0); r_l1 = wave_sum_f(r_l1); r_l2 = wave_sum_f(r_l2);
+      r_cx = wave_sum_f(r_cx); r_cy = wave_sum_f(r_cy);
+      r_xx = wave_sum_f(r_xx); r_xy = wave_sum_f(r_xy); r_yy = wave_sum_f(r_yy);
+      if (lane == 0) {
+        float* d = s_part[k][w];
+        *reinterpret_cast<float4*>(d) = make_float4(r_o, r_l0, r_l1, r_l2);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(r_cx, r_cy, r_xx, r_xy);
+        d[8] = r_yy;
+      }
+    }
+    __syncthreads();
+    // one thread per entry: add the 4 waves in fixed order, write the entry's Gaussian-major slot
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const i64 g = a.tile_list[base + j];
+      const int4 bx = s.box[j];
+      const int ntx = (bx.z >> 4) - (bx.x >> 4) + 1;
+      const i64 e = (i64)tile_off[g] + (i64)(tty - (bx.y >> 4)) * ntx + (ttx - (bx.x >> 4));
+      float* out = partial + e * kGradVals;
+#pragma unroll
+      for (int v = 0; v < kGradVals; ++v)
+        out[v] = ((s_part[j][0][v] + s_part[j][1][v]) + s_part[j][2][v]) + s_part[j][3][v];
+    }
+  }
+}
+
+// per Gaussian: sum its tile slots in order, expand the moments into the four gradients
+__global__ void k_grad_reduce(const float* __restrict__ partial, const int* __restrict__ tile_off,
+                              const float* __restrict__ vinv, i64 n, float* grad_mean, float* grad_vinv,
+                              float* grad_opacity, float* grad_l) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  float r[kGradVals];
+#pragma unroll
+  for (int v = 0; v < kGradVals; ++v) r[v] = 0.0f;
+  for (i64 e = tile_off[g]; e < tile_off[g + 1]; ++e)
+#pragma unroll
+    for (int v = 0; v < kGradVals; ++v) r[v] += partial[e * kGradVals + v];
+  const float A = vinv[4 * g], B = vinv[4 * g + 1], C = vinv[4 * g + 2], D = vinv[4 * g + 3];
+  grad_opacity[g] = r[0];
+  grad_l[3 * g] = r[1]; grad_l[3 * g + 1] = r[2]; grad_l[3 * g + 2] = r[3];
+  // sum common * (d Λ): x0 = dx a + dy c, x1 = dx b + dy d   (gs_model.py:745)
+  grad_mean[2 * g] = r[4] * A + r[5] * C;
+  grad_mean[2 * g + 1] = r[4] * B + r[5] * D;
+  // -0.5 * sum common * d^T d   (gs_model.py:755-758)
+  grad_vinv[4 * g] = -0.5f * r[6];
+  grad_vinv[4 * g + 1] = -0.5f * r[7];
+  grad_vinv[4 * g + 2] = -0.5f * r[7];
+  grad_vinv[4 * g + 3] = -0.5f * r[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// per-pixel CSR export (what torch.sort(stable) + unique give the reference, gs_model.py:546-548)
+// ------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __restrict__ pixel_count,
+                                                     const int* __restrict__ pixel_off,
+                                                     const int* __restrict__ box_off, int* __restrict__ pair_gauss,
+                                                     int* __restrict__ pair_index) {
+  __shared__ int4 s_box[kStage];
+  __shared__ int s_g[kStage];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
+  const int px = (tile % a.tiles_x) * kTile + (lane & 15);
+  const int py = (tile / a.tiles_x) * kTile + w * 4 + (lane >> 4);
+  const bool in_img = px <= a.W && py <= a.H;
+  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  int n = 0;
+  i64 o = 0;
+  if (FILL && in_img) o = pixel_off[(i64)py * (a.W + 1) + px];
+  for (int base = first; base < last; base += kStage) {
+    const int cnt = min(kStage, last - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const i64 g = a.tile_list[base + j];
+      Box b;
+      load_box(a.start, a.end, g, a.W, a.H, b);
+      s_box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
+      s_g[j] = (int)g;
+    }
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const int4 bx = s_box[k];
+      const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+      if (in) {
+        if (FILL) {
+          const int g = s_g[k];
+          pair_gauss[o + n] = g;
+          // position of this pixel in the Gaussian-major rect list (uitility.py:336-366):
+          // row-major inside the box, boxes concatenated in depth order
+          pair_index[o + n] = box_off[g] + (py - bx.y) * (bx.z - bx.x + 1) + (px - bx.x);
+        }
+        ++n;
+      }
+    }
+  }
+  if (!FILL && in_img) pixel_count[(i64)py * (a.W + 1) + px] = n;
+}
+
+__global__ void k_box_sizes(const int* start, const int* end, i64 n, int W, int H, int* size) {
+  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  Box b;
+  size[g] = load_box(start, end, g, W, H, b) ? (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) : 0;
+}
+
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" {
+
+int gcp_tile_grid(int32_t width, int32_t height, int32_t* tiles_x, int32_t* tiles_y) {
+  if (width < 0 || height < 0 || !tiles_x || !tiles_y) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid t = tile_grid(width, height);
+  *tiles_x = t.tx;
+  *tiles_y = t.ty;
+  return GCP_OK;
+}
+
+size_t gcp_scan_i32_workspace_bytes(int64_t n) {
+  return align256((size_t)((n + kScanChunk - 1) / kScanChunk + 1) * sizeof(int));
+}
+
+int gcp_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 0 || !out || (n > 0 && (!in || !ws))) return GCP_ERR_INVALID_ARGUMENT;
+  if (n > 0 && ws_bytes < gcp_scan_i32_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  return launch_excl_scan(in, out, n, (int*)ws, (hipStream_t)stream);
+}
+
+int gcp_bin_tiles_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                        int32_t height, int32_t* tile_off, int64_t* n_tile_pairs_host, void* ws,
+                        size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_gauss < 0 || width < 0 || height < 0 || !tile_off || !n_tile_pairs_host) return GCP_ERR_INVALID_ARGUMENT;
+  *n_tile_pairs_host = 0;
+  if (n_gauss == 0) {
+    GCP_HIP(hipMemsetAsync(tile_off, 0, sizeof(int), stream));
+    return GCP_OK;
+  }
+  if (!start_xy || !end_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  const size_t need = align256((size_t)n_gauss * sizeof(int)) + gcp_scan_i32_workspace_bytes(n_gauss);
+  if (ws_bytes < need) return GCP_ERR_WORKSPACE;
+  int* cnt = (int*)ws;
+  int* sws = (int*)((char*)ws + align256((size_t)n_gauss * sizeof(int)));
+  hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                     (i64)n_gauss, width, height, cnt);
+  GCP_HIP(hipGetLastError());
+  const int st = launch_excl_scan(cnt, tile_off, n_gauss, sws, stream);
+  if (st != GCP_OK) return st;
+  int total = 0;
+  GCP_HIP(hipMemcpyAsync(&total, tile_off + n_gauss, sizeof(int), hipMemcpyDeviceToHost, stream));
+  GCP_HIP(hipStreamSynchronize(stream));
+  *n_tile_pairs_host = total;
+  return GCP_OK;
+}
+
+size_t gcp_bin_workspace_bytes(int64_t n_gauss, int64_t n_tile_pairs) {
+  const int64_t k = n_tile_pairs > 0 ? n_tile_pairs : 1;
+  const int64_t nblk = (k + kSortChunk - 1) / kSortChunk;
+  size_t b = 0;
+  b += 3 * align256((size_t)k * sizeof(unsigned));                 // key A, key B, val B
+  b += 2 * align256((size_t)(256 * nblk + 1) * sizeof(int));       // hist, hist_excl
+  b += gcp_scan_i32_workspace_bytes(256 * nblk);
+  const size_t count_need = align256((size_t)(n_gauss > 0 ? n_gauss : 1) * sizeof(int)) +
+                            gcp_scan_i32_workspace_bytes(n_gauss > 0 ? n_gauss : 1);
+  return b > count_need ? b : count_need;
+}
+
+int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                       int32_t height, const int32_t* tile_off, int64_t n_tile_pairs, int32_t* tile_start,
+                       int32_t* tile_list, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_gauss < 0 || n_tile_pairs < 0 || width < 0 || height < 0 || !tile_start) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  const int n_tiles = tg.tx * tg.ty;
+  const i64 K = n_tile_pairs;
+  if (K == 0) {
+    GCP_HIP(hipMemsetAsync(tile_start, 0, (size_t)(n_tiles + 1) * sizeof(int), stream));
+    return GCP_OK;
+  }
+  if (!start_xy || !end_xy || !tile_off || !tile_list || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_bin_workspace_bytes(n_gauss, K)) return GCP_ERR_WORKSPACE;
+  const i64 nblk = (K + kSortChunk - 1) / kSortChunk;
+  char* p = (char*)ws;
+  unsigned* keyA = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  unsigned* keyB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  unsigned* valB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  int* hist = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* hist_ex = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* sws = (int*)p;
+  unsigned* valA = (unsigned*)tile_list;  // the caller's output buffer doubles as one value buffer
+
+  hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                     (i64)n_gauss, width, height, tg.tx, tile_off, keyA, valA);
+  GCP_HIP(hipGetLastError());
+  int bits = 1;
+  while ((1 << bits) < n_tiles) ++bits;
+  int passes = (bits + 7) / 8;
+  if (passes & 1) ++passes;  // even number of passes: the result lands back in (keyA, valA = tile_list)
+  unsigned *ks = keyA, *vs = valA, *kd = keyB, *vd = valB;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, K, shift, hist, (int)nblk);
+    GCP_HIP(hipGetLastError());
+    const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
+    if (st != GCP_OK) return st;
+    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nblk), dim3(64), 0, stream, ks, vs, kd, vd, K, shift,
+                       (const int*)hist_ex, (int)nblk);
+    GCP_HIP(hipGetLastError());
+    unsigned* t;
+    t = ks; ks = kd; kd = t;
+    t = vs; vs = vd; vd = t;
+  }
+  hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256), 0, stream, ks, K, n_tiles,
+                     tile_start);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+static int make_args(BlendArgs& a, const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
+                     const float* vinv, const float* opacity, const float* l_d, int32_t width, int32_t height,
+                     const int32_t* tile_start, const int32_t* tile_list) {
+  if (width < 0 || height < 0 || !tile_start) return GCP_ERR_INVALID_ARGUMENT;
+  a.start = start_xy; a.end = end_xy; a.mean = mean_xy; a.vinv = vinv; a.opacity = opacity; a.l_d = l_d;
+  a.tile_start = tile_start; a.tile_list = (const unsigned*)tile_list;
+  a.W = width; a.H = height; a.tiles_x = tile_grid(width, height).tx;
+  return GCP_OK;
+}
+
+int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy, const float* vinv,
+                      const float* opacity, const float* l_d, int64_t n_gauss, int32_t width, int32_t height,
+                      const int32_t* tile_start, const int32_t* tile_list, float* image, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlendArgs a;
+  const int st = make_args(a, start_xy, end_xy, mean_xy, vinv, opacity, l_d, width, height, tile_start, tile_list);
+  if (st != GCP_OK || !image || n_gauss < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss > 0 && (!start_xy || !end_xy || !mean_xy || !vinv || !opacity || !l_d)) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, image);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs) {
+  return align256((size_t)(n_tile_pairs > 0 ? n_tile_pairs : 1) * kGradVals * sizeof(float));
+}
+
+int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy, const float* vinv,
+                       const float* opacity, const float* l_d, int64_t n_gauss, int32_t width, int32_t height,
+                       const int32_t* tile_off, int64_t n_tile_pairs, const int32_t* tile_start,
+                       const int32_t* tile_list, const float* image, const float* grad_image, float* grad_mean,
+                       float* grad_vinv, float* grad_opacity, float* grad_l, void* ws, size_t ws_bytes,
+                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlendArgs a;
+  const int st = make_args(a, start_xy, end_xy, mean_xy, vinv, opacity, l_d, width, height, tile_start, tile_list);
+  if (st != GCP_OK || n_gauss < 0 || n_tile_pairs < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !mean_xy || !vinv || !opacity || !l_d || !tile_off || !image || !grad_image ||
+      !grad_mean || !grad_vinv || !grad_opacity || !grad_l || !ws)
+    return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_blend_backward_workspace_bytes(n_tile_pairs)) return GCP_ERR_WORKSPACE;
+  const TileGrid tg = tile_grid(width, height);
+  float* partial = (float*)ws;
+  if (n_tile_pairs > 0) {
+    hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, tile_off, image,
+                       grad_image, partial);
+    GCP_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)partial, tile_off, vinv, (i64)n_gauss, grad_mean, grad_vinv, grad_opacity, grad_l);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                          int32_t height, const int32_t* tile_start, const int32_t* tile_list,
+                          int32_t* pixel_count, int32_t* box_size, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlendArgs a;
+  const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
+  if (st != GCP_OK || !pixel_count || !box_size || n_gauss < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss > 0 && (!start_xy || !end_xy)) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  hipLaunchKernelGGL((k_pixel_lists<false>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, pixel_count,
+                     (const int*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  GCP_HIP(hipGetLastError());
+  if (n_gauss > 0) {
+    hipLaunchKernelGGL(k_box_sizes, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                       (i64)n_gauss, width, height, box_size);
+    GCP_HIP(hipGetLastError());
+  }
+  return GCP_OK;
+}
+
+int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                         int32_t height, const int32_t* tile_start, const int32_t* tile_list,
+                         const int32_t* pixel_off, const int32_t* box_off, int32_t* pair_gauss,
+                         int32_t* pair_index, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlendArgs a;
+  const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
+  if (st != GCP_OK || n_gauss < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !pixel_off || !box_off || !pair_gauss || !pair_index) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  hipLaunchKernelGGL((k_pixel_lists<true>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, (int*)nullptr,
+                     pixel_off, box_off, pair_gauss, pair_index);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+}  // extern "C"

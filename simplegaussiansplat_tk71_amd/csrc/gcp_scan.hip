@@ -41,13 +41,22 @@
 #include <stdlib.h>
 #include <mutex>
 
+#include "gcp_device.hpp"
 #include "grouped_cumprod_hip.h"
 
+namespace gcp {
+thread_local int t_last_hip_error = 0;
+int hip_fail(hipError_t e) {
+  t_last_hip_error = (int)e;
+  return GCP_ERR_HIP;
+}
+}  // namespace gcp
+
 namespace {
+using namespace gcp;
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
-typedef long long i64;
 
 enum : int { M_CUMPROD_FWD = 0, M_CUMSUM_FWD = 1, M_CUMPROD_BWD = 2, M_CUMSUM_REV = 3 };
 
@@ -93,25 +102,6 @@ struct ScanArgs {
   unsigned* hdr;      // [2] = unresolved tiles of the last launch (introspection only)
   int xcd_remap;
 };
-
-// ----------------------------------------------------------------------------
-// DPP helpers (gfx9 encodings: row_shr:n = 0x110+n, wave_shr:1 = 0x138,
-// row_bcast:15 = 0x142, row_bcast:31 = 0x143).  bound_ctrl = 0: a lane whose
-// source is out of range (or whose row is masked off) keeps `old`.
-// ----------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float old, float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
-                                         CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int old, int v) {
-  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 
 // Inclusive segmented scan of one value per lane.  `h` = nearest lane <= this
 // one that starts a segment, -1 if none: lane l may absorb lane s iff s >= h.
@@ -611,18 +601,6 @@ __global__ void gcp_check_groups_kernel(const int* inv, const int* inv_len, i64 
 // ----------------------------------------------------------------------------
 // Host side
 // ----------------------------------------------------------------------------
-thread_local int t_last_hip_error = 0;
-
-inline int hip_fail(hipError_t e) {
-  t_last_hip_error = (int)e;
-  return GCP_ERR_HIP;
-}
-#define GCP_HIP(call)                                   \
-  do {                                                  \
-    hipError_t e_ = (call);                             \
-    if (e_ != hipSuccess) return hip_fail(e_);          \
-  } while (0)
-
 inline i64 ws_tiles(i64 n) { return (n + 1023) / 1024; }  // upper bound for any tile size
 
 size_t ws_bytes_for(i64 n) {
@@ -717,7 +695,7 @@ extern "C" {
 
 int gcp_abi_version(void) { return GCP_ABI_VERSION; }
 
-int gcp_last_hip_error(void) { return t_last_hip_error; }
+int gcp_last_hip_error(void) { return gcp::t_last_hip_error; }
 
 const char* gcp_status_string(int status) {
   switch (status) {

@@ -1,0 +1,195 @@
+"""Tile binning and fused alpha blending on the HIP library.
+
+Host side of csrc/gcp_raster.hip: allocates buffers with torch, passes raw pointers through the C ABI
+(include/grouped_cumprod_hip.h).  Everything the reference does around its scan in
+`custom_autograd_grouped_cumprod` (reference: gs_model.py:598-663) happens in three launches here:
+bin (f2), blend forward (f1), blend backward (f1).  No CPU path.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+TILE = 16
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev_tensor(t, name, dtype, shape_tail=None):
+    _require(isinstance(t, torch.Tensor), f"{name}: expected a torch.Tensor")
+    _require(t.is_cuda, f"{name}: expected a ROCm device tensor, got {t.device} (no CPU path)")
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    t = t.contiguous()
+    if shape_tail is not None:
+        _require(tuple(t.shape[1:]) == tuple(shape_tail), f"{name}: shape {tuple(t.shape)}, expected [N,{shape_tail}]")
+    return t
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+@dataclass
+class TileBins:
+    """Per-tile depth-ordered Gaussian lists of one image (the f2 product)."""
+    width: int
+    height: int
+    n_gauss: int
+    n_tile_pairs: int
+    tiles_x: int
+    tiles_y: int
+    tile_off: torch.Tensor    # int32[N+1]  first Gaussian-major entry of every Gaussian
+    tile_start: torch.Tensor  # int32[n_tiles+1] first sorted entry of every tile
+    tile_list: torch.Tensor   # int32[K] Gaussian ids, tile-major, depth order inside a tile
+
+
+def bin_tiles(startpoint, endpoint, width, height):
+    """startpoint/endpoint: int [N,2] (x,y) inclusive boxes in depth order."""
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    n = start.size(0)
+    _require(end.size(0) == n, "endpoint: row count differs from startpoint")
+    dev = start.device
+    width, height = int(width), int(height)
+    lib = _lib.load()
+    tx, ty = ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(lib.gcp_tile_grid(width, height, ctypes.byref(tx), ctypes.byref(ty)), "gcp_tile_grid")
+    n_tiles = tx.value * ty.value
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        tile_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_bin_workspace_bytes(n, 0), dtype=torch.uint8, device=dev)
+        k = ctypes.c_int64(0)
+        _lib.check(
+            lib.gcp_bin_tiles_count(start.data_ptr(), end.data_ptr(), n, width, height, tile_off.data_ptr(),
+                                    ctypes.byref(k), ws.data_ptr(), ws.numel(), st),
+            "gcp_bin_tiles_count",
+        )
+        K = k.value
+        tile_start = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+        tile_list = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_bin_workspace_bytes(n, K), dtype=torch.uint8, device=dev)
+        _lib.check(
+            lib.gcp_bin_tiles_fill(start.data_ptr(), end.data_ptr(), n, width, height, tile_off.data_ptr(), K,
+                                   tile_start.data_ptr(), tile_list.data_ptr(), ws.data_ptr(), ws.numel(), st),
+            "gcp_bin_tiles_fill",
+        )
+    return TileBins(width, height, n, K, tx.value, ty.value, tile_off, tile_start, tile_list[:K])
+
+
+def _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d):
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    mean_f = _dev_tensor(mean, "mean", torch.float32, (2,))  # reference: mean.to(torch.float32), gs_model.py:679
+    vinv = _dev_tensor(variance_inverse, "variance_inverse", torch.float32, (2, 2))
+    n = start.size(0)
+    op = _dev_tensor(opacity, "opacity", torch.float32).reshape(-1)
+    col = _dev_tensor(l_d, "l_d", torch.float32, (3,))
+    for t, name in ((end, "endpoint"), (mean_f, "mean"), (vinv, "variance_inverse"), (op, "opacity"), (col, "l_d")):
+        _require(t.size(0) == n, f"{name}: {t.size(0)} rows, expected {n}")
+        _require(t.device == start.device, f"{name}: on {t.device}, expected {start.device}")
+    return start, end, mean_f, vinv, op, col
+
+
+def blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d):
+    """-> image f32[(H+1),(W+1),3] (reference layout, gs_model.py:505)."""
+    start, end, mean_f, vinv, op, col = _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d)
+    dev = start.device
+    lib = _lib.load()
+    image = torch.empty(bins.height + 1, bins.width + 1, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            lib.gcp_blend_forward(start.data_ptr(), end.data_ptr(), mean_f.data_ptr(), vinv.data_ptr(), op.data_ptr(),
+                                  col.data_ptr(), bins.n_gauss, bins.width, bins.height, bins.tile_start.data_ptr(),
+                                  bins.tile_list.data_ptr(), image.data_ptr(), _stream(dev)),
+            "gcp_blend_forward",
+        )
+    return image
+
+
+def blend_backward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, image, grad_image):
+    """-> (grad_mean [N,2], grad_variance_inverse [N,2,2], grad_opacity [N,1], grad_l_d [N,3])."""
+    start, end, mean_f, vinv, op, col = _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d)
+    dev = start.device
+    n = bins.n_gauss
+    img = _dev_tensor(image, "image", torch.float32)
+    gimg = _dev_tensor(grad_image, "grad_image", torch.float32)
+    shape = (bins.height + 1, bins.width + 1, 3)
+    _require(tuple(img.shape) == shape and tuple(gimg.shape) == shape, f"image / grad_image: expected shape {shape}")
+    lib = _lib.load()
+    g_mean = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    g_vinv = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
+    g_op = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    g_l = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.gcp_blend_backward_workspace_bytes(bins.n_tile_pairs), dtype=torch.uint8, device=dev)
+        _lib.check(
+            lib.gcp_blend_backward(start.data_ptr(), end.data_ptr(), mean_f.data_ptr(), vinv.data_ptr(), op.data_ptr(),
+                                   col.data_ptr(), n, bins.width, bins.height, bins.tile_off.data_ptr(),
+                                   bins.n_tile_pairs, bins.tile_start.data_ptr(), bins.tile_list.data_ptr(),
+                                   img.data_ptr(), gimg.data_ptr(), g_mean.data_ptr(), g_vinv.data_ptr(),
+                                   g_op.data_ptr(), g_l.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            "gcp_blend_backward",
+        )
+    return g_mean, g_vinv, g_op, g_l
+
+
+def exclusive_scan_i32(x):
+    """int32[n] -> int32[n+1] exclusive prefix sums (last entry = total)."""
+    x = _dev_tensor(x, "x", torch.int32)
+    dev = x.device
+    lib = _lib.load()
+    out = torch.empty(x.numel() + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.gcp_scan_i32_workspace_bytes(x.numel()), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_exclusive_scan_i32(x.data_ptr(), out.data_ptr(), x.numel(), ws.data_ptr(), ws.numel(),
+                                              _stream(dev)), "gcp_exclusive_scan_i32")
+    return out
+
+
+@dataclass
+class PixelLists:
+    """Per-pixel CSR of the splat-pixel pairs: what the reference obtains from `unique` + a stable
+    sort of M pixel keys (gs_model.py:546-548), built from the tile lists instead."""
+    pixel_off: torch.Tensor   # int32[P+1], P = (H+1)*(W+1) pixels row-major (= ascending key y*10000+x)
+    pair_gauss: torch.Tensor  # int32[M] Gaussian of every pair, pixel-major, depth order inside a pixel
+    pair_index: torch.Tensor  # int32[M] == `index` of torch.sort(key, stable=True) (gs_model.py:547)
+    box_off: torch.Tensor     # int32[N+1] first Gaussian-major pair of every Gaussian
+
+
+def pixel_lists(bins, startpoint, endpoint):
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    dev = start.device
+    lib = _lib.load()
+    n_pix = (bins.height + 1) * (bins.width + 1)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        count = torch.empty(n_pix, dtype=torch.int32, device=dev)
+        bsize = torch.empty(max(bins.n_gauss, 1), dtype=torch.int32, device=dev)
+        _lib.check(
+            lib.gcp_pixel_lists_count(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
+                                      bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), count.data_ptr(),
+                                      bsize.data_ptr(), st),
+            "gcp_pixel_lists_count",
+        )
+        pixel_off = exclusive_scan_i32(count)
+        box_off = exclusive_scan_i32(bsize[: bins.n_gauss])
+        m = int(pixel_off[-1].item())
+        _require(m == int(box_off[-1].item()), "pixel lists: pair count mismatch between pixel- and box-major views")
+        pair_gauss = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        pair_index = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        _lib.check(
+            lib.gcp_pixel_lists_fill(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
+                                     bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), pixel_off.data_ptr(),
+                                     box_off.data_ptr(), pair_gauss.data_ptr(), pair_index.data_ptr(), st),
+            "gcp_pixel_lists_fill",
+        )
+    return PixelLists(pixel_off, pair_gauss[:m], pair_index[:m], box_off)

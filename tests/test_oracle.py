@@ -162,3 +162,25 @@ def test_empty_inputs():
     assert co.cumsum_forward(e, k).numel() == 0
     assert co.cumprod_backward(e, e, e, k, k).numel() == 0
     assert tp.grouped_cumprod(e, k).numel() == 0
+
+
+@pytest.mark.parametrize("name", ["fn_6g_16x12", "fn_200g_64x48"])
+def test_dense_renderer_vs_reference_function_golden(name):
+    """a7: the dense autograd restatement reproduces the image and the opacity / precision-matrix
+    gradients the reference's own Function produced (single chunk = the parity contract).  The
+    reference's colour gradient is channel-collapsed (gs_model.py:710-712, :763-766): the golden holds
+    it as informational, and the dense oracle's is the hypothesis sum_pairs(g.p)/l_c of SURVEY §0 Q2."""
+    from oracle import dense_render as dr
+
+    z = np.load(os.path.join(GOLD, "function_golden.npz"))
+    g = lambda k: torch.from_numpy(z[f"{name}/{k}"])  # noqa: E731
+    w, h = (int(v) for v in z[name + "/width_height"])
+    img, gv, go, gl = dr.render_with_grads(g("start"), g("end"), g("mean"), g("vinv"), g("opacity"), g("l_d"), w, h, g("wimg"))
+    torch.testing.assert_close(img.float(), g("image"), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(go.float(), g("grad_opacity"), atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(gv.float(), g("grad_vinv"), atol=2e-5, rtol=1e-4)
+    # fp32 forward of the same restatement
+    img32 = dr.render(g("start"), g("end"), g("mean"), g("vinv"), g("opacity"), g("l_d"), w, h)
+    torch.testing.assert_close(img32, g("image"), atol=1e-5, rtol=1e-5)
+    # the reference's colour gradient differs from the true one by design
+    assert not torch.allclose(gl.float(), g("grad_l_REFERENCE_BUGGY"), atol=1e-3, rtol=1e-2)

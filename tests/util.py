@@ -73,3 +73,29 @@ def assert_parity(got, want32, scale, what="", tol=TOL):
             f"got {got[i].item():.9g} want {want[i].item():.9g} scale {scale[i].item():.4g}; "
             f"max err {err.max().item():.3g}"
         )
+
+
+def make_scene(n_gauss, width, height, max_half, seed, opacity_one_every=0):
+    """Gaussians of one camera in depth order, as `custom_autograd_grouped_cumprod` receives them
+    (reference: gs_model.py:419-425, :449): integer means, inclusive integer boxes clamped to the image."""
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.stack(
+        [torch.randint(0, width + 1, (n_gauss,), generator=g), torch.randint(0, height + 1, (n_gauss,), generator=g)], 1
+    ).to(torch.int32)
+    half = torch.randint(1, max_half + 1, (n_gauss, 2), generator=g).to(torch.int32)
+    lim = torch.tensor([width, height], dtype=torch.int32)
+    start = torch.minimum((mean - half).clamp(min=0), lim)
+    end = torch.minimum((mean + half).clamp(min=0), lim)
+    boxsize = torch.prod((end - start + 1).to(torch.int64), dim=1)
+    sx = 0.6 + 0.35 * max_half * torch.rand(n_gauss, generator=g)
+    sy = 0.6 + 0.35 * max_half * torch.rand(n_gauss, generator=g)
+    rho = 0.8 * (torch.rand(n_gauss, generator=g) - 0.5)
+    cov = torch.stack([sx * sx, rho * sx * sy, rho * sx * sy, sy * sy], 1).reshape(-1, 2, 2)
+    vinv = torch.linalg.inv(cov).to(torch.float32).contiguous()
+    opacity = (0.05 + 0.9 * torch.rand(n_gauss, 1, generator=g)).to(torch.float32)
+    if opacity_one_every:
+        opacity[::opacity_one_every] = 1.0  # alpha == 1 at the centre pixel: inclusive product exactly 0
+    l_d = (0.05 + 0.95 * torch.rand(n_gauss, 3, generator=g)).to(torch.float32)
+    wimg = torch.randn(height + 1, width + 1, 3, generator=g)
+    return dict(boxsize=boxsize, start=start, end=end, mean=mean, vinv=vinv, opacity=opacity, l_d=l_d, wimg=wimg,
+                width=width, height=height)

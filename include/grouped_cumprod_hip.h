@@ -28,9 +28,10 @@
  * gcp_workspace_bytes(n) bytes of scratch.  Pass ws == NULL to let the library
  * use an internal per-device scratch buffer (grown with hipMalloc on demand —
  * not graph-capturable, and not safe for concurrent launches on two streams).
- * A caller-provided workspace must be prepared ONCE with gcp_workspace_init()
- * before its first use (and again after any failed call); it may then be
- * reused by any number of calls that are ordered on one stream.
+ * A caller-provided workspace needs no initialisation (the fallback is stateless;
+ * gcp_workspace_init() is kept for ABI stability and only clears the
+ * introspection counter) and may be reused by any number of calls that are
+ * ordered on one stream.
  */
 #ifndef GROUPED_CUMPROD_HIP_H
 #define GROUPED_CUMPROD_HIP_H
@@ -113,6 +114,23 @@ int gcp_cumprod_backward(const float* param, const float* param_cumprod,
  */
 int gcp_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t n,
                        void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Exact chunk carry.  Same scans, but group g starts from carry[g]
+ * instead of the identity: y[i] = carry[inv[i]] (*|+) scan.  `inv` must be the DENSE group id
+ * (it indexes `carry`, f32[n_groups]).  A caller that splits every pixel's depth-sorted list
+ * into memory chunks (reference: gs_model.py:428, :675-686 forward, :634-643 backward) passes
+ * the previous chunk's last inclusive value per pixel and gets the single-chunk result
+ * exactly; the reference's own carry drops one factor per chunk boundary (its `amin` of the
+ * EXCLUSIVE transmittance, gs_model.py:582-586).  For the reverse form the carry
+ * is the suffix sum entering from the deeper chunk.  Traffic: 12 B / element + 4 B / group.
+ */
+int gcp_cumprod_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y,
+                              int64_t n, int64_t n_groups, void* ws, size_t ws_bytes, void* stream);
+int gcp_cumsum_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y,
+                             int64_t n, int64_t n_groups, void* ws, size_t ws_bytes, void* stream);
+int gcp_cumsum_reverse_carry(const float* x, const int32_t* inv, const float* carry, float* y,
+                             int64_t n, int64_t n_groups, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Debug aid (synchronises `stream`): checks that `inv` is a dense

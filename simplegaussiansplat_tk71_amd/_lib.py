@@ -24,6 +24,9 @@ SIGNATURES = {
     "gcp_cumprod_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_reverse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumprod_forward_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_forward_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_reverse_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumprod_backward": (
         ctypes.c_int,
         [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _c_void_p, _sz, _c_void_p],

@@ -95,6 +95,7 @@ struct ScanArgs {
   const float* in1;  // param_cumprod (a3 only)
   const float* in2;  // grad_out (a3 only)
   const int* key;    // pixel key (a1/a2) or dense group id `inv` (a3)
+  const float* carry;  // optional per-group prefix (indexed by `key`, which must then be the dense group id)
   float* out;
   i64 n;
   i64 ntiles;
@@ -196,7 +197,7 @@ __device__ __forceinline__ i64 logical_tile(i64 b, i64 ntiles, int xcd_remap) {
 // ----------------------------------------------------------------------------
 // Main kernel: one tile per block.
 // ----------------------------------------------------------------------------
-template <int MODE, bool ALIGNED, bool FULL>
+template <int MODE, bool ALIGNED, bool FULL, bool CARRY>
 __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float* s_wv, int* s_wf,
                                           float* s_tc, int* s_fh) {
   typedef Mode<MODE> MD;
@@ -308,6 +309,13 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       f2 = val[2] && (!pex[2] || kk[r].z != kk[r].y);
       f3 = val[3] && (!pex[3] || kk[r].w != kk[r].z);
     }
+    if constexpr (CARRY) {
+      // exact chunk carry: the value entering group g is carry[g]; fold it into the head element
+      if (f0) v[r].x = M::op(a.carry[kk[r].x], v[r].x);
+      if (f1) v[r].y = M::op(a.carry[kk[r].y], v[r].y);
+      if (f2) v[r].z = M::op(a.carry[kk[r].z], v[r].z);
+      if (f3) v[r].w = M::op(a.carry[kk[r].w], v[r].w);
+    }
     const float s0 = v[r].x;
     const float s1 = f1 ? v[r].y : M::op(s0, v[r].y);
     const float s2 = f2 ? v[r].z : M::op(s1, v[r].z);
@@ -403,6 +411,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         }
       }
       if (!done) { unresolved = 1; tc = id; }  // the fix-up kernel folds the true prefix in later
+      if constexpr (CARRY) {
+        // group start found behind the tile (first element is not a head): its carry belongs to the prefix
+        const bool first_is_head = nb_exists ? (nbk != k0) : true;
+        if (done && !first_is_head) tc = M::op(a.carry[k0], tc);
+      }
     }
     if (lane == 0) { s_tc[0] = tc; s_wf[kWaves] = unresolved; }
   }
@@ -460,7 +473,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   }
 }
 
-template <int MODE, bool ALIGNED>
+template <int MODE, bool ALIGNED, bool CARRY>
 __global__ __launch_bounds__(kThreads) void gcp_scan_main(const ScanArgs a) {
   __shared__ float s_wv[kWaves];
   __shared__ int s_wf[kWaves + 1];
@@ -468,8 +481,8 @@ __global__ __launch_bounds__(kThreads) void gcp_scan_main(const ScanArgs a) {
   __shared__ int s_fh[kWaves];
   const i64 lt = logical_tile((i64)blockIdx.x, a.ntiles, a.xcd_remap);
   const i64 pt = Mode<MODE>::kRev ? (a.ntiles - 1 - lt) : lt;
-  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true>(a, lt, s_wv, s_wf, s_tc, s_fh);
-  else scan_tile<MODE, ALIGNED, false>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true, CARRY>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  else scan_tile<MODE, ALIGNED, false, CARRY>(a, lt, s_wv, s_wf, s_tc, s_fh);
 }
 
 // ----------------------------------------------------------------------------
@@ -646,7 +659,7 @@ int env_int(const char* name, int dflt) {
 
 template <int MODE>
 int launch_scan(const float* in0, const float* in1, const float* in2, const int* key, float* out,
-                i64 n, void* ws, size_t ws_bytes, void* stream_) {
+                i64 n, void* ws, size_t ws_bytes, void* stream_, const float* carry = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n == 0) return GCP_OK;
@@ -665,7 +678,7 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   const i64 t = ws_tiles(n);
   char* p = (char*)ws;
   ScanArgs a;
-  a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out;
+  a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry;
   a.n = n; a.ntiles = ntiles;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
   a.desc = (uint2*)p;
@@ -678,8 +691,17 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   const bool aligned = (al & 15u) == 0;
 
   const dim3 grid((unsigned)ntiles), block(kThreads);
-  if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((gcp_scan_main<MODE, false>), grid, block, 0, stream, a);
+  if constexpr (Mode<MODE>::kBwd) {
+    if (carry) return GCP_ERR_INVALID_ARGUMENT;
+    if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false>), grid, block, 0, stream, a);
+  } else if (carry) {
+    if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gcp_scan_main<MODE, false, true>), grid, block, 0, stream, a);
+  } else {
+    if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false>), grid, block, 0, stream, a);
+  }
   GCP_HIP(hipGetLastError());
   if (ntiles > 1) {
     const unsigned fb = (unsigned)(ntiles < kFixBlocks ? ntiles : kFixBlocks);
@@ -728,6 +750,24 @@ int gcp_cumsum_forward(const float* x, const int32_t* key, float* y, int64_t n, 
 int gcp_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t n, void* ws,
                        size_t ws_bytes, void* stream) {
   return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, key, y, n, ws, ws_bytes, stream);
+}
+
+int gcp_cumprod_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
+                              int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMPROD_FWD>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
+}
+
+int gcp_cumsum_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
+                             int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMSUM_FWD>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
+}
+
+int gcp_cumsum_reverse_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
+                             int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
 }
 
 int gcp_cumprod_backward(const float* param, const float* param_cumprod, const float* grad_out,

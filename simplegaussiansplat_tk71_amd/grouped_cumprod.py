@@ -26,6 +26,9 @@ __all__ = [
     "grouped_cumsum_forward",
     "grouped_cumprod_backward",
     "grouped_cumsum_reverse",
+    "grouped_cumprod_forward_carry",
+    "grouped_cumsum_forward_carry",
+    "grouped_cumsum_reverse_carry",
     "check_groups",
     "last_fallback_tiles",
     "tile_elems",
@@ -101,6 +104,36 @@ def grouped_cumsum_reverse(x, key, out):
     """Suffix sums inside each run: flip -> grouped_cumsum_forward -> flip of the
     reference (gs_model.py:716-722) in one pass.  Not in the reference module."""
     _forward("gcp_cumsum_reverse", x, key, out)
+
+
+def _forward_carry(fn_name, x, inv, carry, y):
+    _require(isinstance(inv, torch.Tensor), "inv: expected a torch.Tensor")
+    n = inv.numel()
+    dev = inv.device
+    _check_tensor(inv, "inv", torch.int32, dev)
+    _check_tensor(x, "x", torch.float32, dev, n)
+    _check_tensor(y, "out", torch.float32, dev, n)
+    _check_tensor(carry, "carry", torch.float32, dev)
+    if n == 0:
+        return
+    _require(carry.numel() > 0, "carry: empty for a non-empty input")
+    _launch(fn_name, dev, n, (x.data_ptr(), inv.data_ptr(), carry.data_ptr(), y.data_ptr()), (carry.numel(),))
+
+
+def grouped_cumprod_forward_carry(x, inv, carry, out):
+    """out[i] = carry[inv[i]] * prod of x over the group up to i (`inv` = dense group id).  Exact version
+    of the reference's chunk carry (gs_model.py:606-615).  Not in the reference module."""
+    _forward_carry("gcp_cumprod_forward_carry", x, inv, carry, out)
+
+
+def grouped_cumsum_forward_carry(x, inv, carry, out):
+    _forward_carry("gcp_cumsum_forward_carry", x, inv, carry, out)
+
+
+def grouped_cumsum_reverse_carry(x, inv, carry, out):
+    """Suffix sums that start from carry[inv[i]] (the suffix entering from a deeper chunk,
+    gs_model.py:634-643)."""
+    _forward_carry("gcp_cumsum_reverse_carry", x, inv, carry, out)
 
 
 def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_len):

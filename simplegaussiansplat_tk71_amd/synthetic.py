@@ -92,3 +92,38 @@ def make_config(name, seed=0, device="cpu", rows=None, row_start=0):
     c = CONFIGS[name]
     h = c["height"] if rows is None else rows
     return make_pairs(h, c["width"], c["mean_depth"], c["deep"], seed, device, row_start)
+
+
+def make_scene(n_gauss, width, height, mean_depth, seed=0, device="cpu"):
+    """Function-level synthetic input: Gaussians of one camera in depth order
+    (= index order) as `custom_autograd_grouped_cumprod` receives them (reference: gs_model.py:419-425,
+    :449).  Integer centres uniform in the image; half-sizes drawn so that the mean box area is
+    P*D/N pixels, i.e. the pair list has mean depth D."""
+    device = torch.device(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    p = (width + 1) * (height + 1)
+    area = max(1.0, p * float(mean_depth) / n_gauss)
+    side = area ** 0.5                      # mean (2h+1)
+    hmean = max(0.5, (side - 1.0) / 2.0)
+    half = (torch.rand(n_gauss, 2, device=device, generator=g) * 2.0 * hmean).round().to(torch.int32)
+    mean = torch.stack([torch.randint(0, width + 1, (n_gauss,), device=device, generator=g),
+                        torch.randint(0, height + 1, (n_gauss,), device=device, generator=g)], 1).to(torch.int32)
+    lim = torch.tensor([width, height], dtype=torch.int32, device=device)
+    start = torch.minimum((mean - half).clamp(min=0), lim)
+    end = torch.minimum((mean + half).clamp(min=0), lim)
+    boxsize = torch.prod((end - start + 1).to(torch.int64), dim=1)
+    sig = (0.6 + 0.45 * half.float() * (0.5 + torch.rand(n_gauss, 2, device=device, generator=g)))
+    rho = 0.8 * (torch.rand(n_gauss, device=device, generator=g) - 0.5)
+    sx, sy = sig[:, 0], sig[:, 1]
+    det = (sx * sy) ** 2 * (1 - rho * rho)
+    vinv = torch.stack([sy * sy / det, -rho * sx * sy / det, -rho * sx * sy / det, sx * sx / det], 1).reshape(-1, 2, 2)
+    opacity = torch.sigmoid(torch.randn(n_gauss, 1, device=device, generator=g) * 2.0 + 1.7).clamp_(0.005, 0.995)
+    l_d = 0.05 + 0.95 * torch.rand(n_gauss, 3, device=device, generator=g)
+    return dict(boxsize=boxsize, start=start, end=end, mean=mean, vinv=vinv.contiguous(), opacity=opacity, l_d=l_d,
+                width=width, height=height)
+
+
+def make_scene_config(name, seed=0, device="cpu"):
+    c = CONFIGS[name]
+    return make_scene(c["gaussians"], c["width"] - 1, c["height"] - 1, c["mean_depth"], seed, device)

@@ -41,11 +41,19 @@ using namespace gcp;
 
 constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
-constexpr int kStageBwd = 128;      // (backward; LDS also holds the per-wave partial sums)
+constexpr int kStageBwd = 32;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kGradVals = 9;        // go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
-constexpr int kGradStride = 12;     // floats per partial slot in LDS (16-byte aligned)
 constexpr int kSortChunk = 2048;    // keys per radix block
 constexpr int kScanChunk = 2048;    // ints per prefix-sum block
+
+// sum over each 16-lane DPP row (= one pixel row of the tile); valid in lanes 15, 31, 47, 63
+__device__ __forceinline__ float row_sum16(float v) {
+  v += dpp_f<0x111, 0xf>(0.0f, v);
+  v += dpp_f<0x112, 0xf>(0.0f, v);
+  v += dpp_f<0x114, 0xf>(0.0f, v);
+  v += dpp_f<0x118, 0xf>(0.0f, v);
+  return v;
+}
 
 struct TileGrid { int tx, ty; };
 inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTile - 1) / kTile, (H + 1 + kTile - 1) / kTile}; }
@@ -233,7 +241,7 @@ struct BlendArgs {
 template <int STAGE>
 struct Staged {
   int4 box[STAGE];
-  float4 geo[STAGE];   // mx, my, opacity, -
+  float4 geo[STAGE];   // mx, my, opacity, 1/opacity (0 if opacity == 0)
   float4 vin[STAGE];   // a b c d  (Λ = [[a,b],[c,d]])
   float4 col[STAGE];   // l0 l1 l2 -
 };
@@ -245,7 +253,8 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     Box b;
     load_box(a.start, a.end, g, a.W, a.H, b);
     s.box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
-    s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], a.opacity[g], 0.0f);
+    const float op = a.opacity[g];
+    s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], op, op != 0.0f ? 1.0f / op : 0.0f);
     s.vin[j] = make_float4(a.vinv[4 * g], a.vinv[4 * g + 1], a.vinv[4 * g + 2], a.vinv[4 * g + 3]);
     s.col[j] = make_float4(a.l_d[3 * g], a.l_d[3 * g + 1], a.l_d[3 * g + 2], 0.0f);
   }
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
                                                    const float* __restrict__ grad_image,
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   __shared__ Staged<kStageBwd> s;
-  __shared__ __attribute__((aligned(16))) float s_part[kStageBwd][4][kGradStride];
+  __shared__ float s_part[kStageBwd][16][kGradVals];  // [entry][pixel row of the tile][value]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int ttx = tile % a.tiles_x, tty = tile / a.tiles_x;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const int4 bx = s.box[k];
       const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
       if (__ballot(in) == 0ull) {
-        if (lane < kGradStride) s_part[k][w][lane] = 0.0f;
+        if (lane < 4 * kGradVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
         continue;
       }
       float r_o = 0.0f, r_l0 = 0.0f, r_l1 = 0.0f, r_l2 = 0.0f, r_cx = 0.0f, r_cy = 0.0f, r_xx = 0.0f, r_xy = 0.0f,
@@ -345,8 +354,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
           const float gp = g0 * (wgt * co.x) + g1 * (wgt * co.y) + g2 * (wgt * co.z);  // gs_model.py:632
           acc += gp;
           const float S = gC - acc;                 // exclusive suffix sum of gp (gs_model.py:716-722)
-          const float sa = S / anti;
-          r_o = -(g * sa) + (op != 0.0f ? gp / op : 0.0f);          // gs_model.py:733-740
+          const float sa = S * __builtin_amdgcn_rcpf(anti);          // S / anti (v_rcp_f32, 1 ulp)
+          r_o = -(g * sa) + gp * ge.w;                              // gs_model.py:733-740 (gp / o, o != 0)
           r_l0 = g0 * wgt; r_l1 = g1 * wgt; r_l2 = g2 * wgt;        // true dL/dl (reference: gp / l, Q2)
           const float common = gp - (op * g) * sa;                  // gs_model.py:747-748, :757-758
           r_cx = common * dx; r_cy = common * dy;
@@ -354,19 +363,17 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         }
         T = incl;
       }
-      r_o = wave_sum_f(r_o);
-      r_l0 = wave_sum_f(r_l0); r_l1 = wave_sum_f(r_l1); r_l2 = wave_sum_f(r_l2);
-      r_cx = wave_sum_f(r_cx); r_cy = wave_sum_f(r_cy);
-      r_xx = wave_sum_f(r_xx); r_xy = wave_sum_f(r_xy); r_yy = wave_sum_f(r_yy);
-      if (lane == 0) {
-        float* d = s_part[k][w];
-        *reinterpret_cast<float4*>(d) = make_float4(r_o, r_l0, r_l1, r_l2);
-        *reinterpret_cast<float4*>(d + 4) = make_float4(r_cx, r_cy, r_xx, r_xy);
-        d[8] = r_yy;
+      r_o = row_sum16(r_o);
+      r_l0 = row_sum16(r_l0); r_l1 = row_sum16(r_l1); r_l2 = row_sum16(r_l2);
+      r_cx = row_sum16(r_cx); r_cy = row_sum16(r_cy);
+      r_xx = row_sum16(r_xx); r_xy = row_sum16(r_xy); r_yy = row_sum16(r_yy);
+      if ((lane & 15) == 15) {
+        float* d = s_part[k][w * 4 + (lane >> 4)];
+        d[0] = r_o; d[1] = r_l0; d[2] = r_l1; d[3] = r_l2; d[4] = r_cx; d[5] = r_cy; d[6] = r_xx; d[7] = r_xy; d[8] = r_yy;
       }
     }
     __syncthreads();
-    // one thread per entry: add the 4 waves in fixed order, write the entry's Gaussian-major slot
+    // one thread per entry: add the 16 pixel rows in fixed order, write the entry's Gaussian-major slot
     for (int j = threadIdx.x; j < cnt; j += 256) {
       const i64 g = a.tile_list[base + j];
       const int4 bx = s.box[j];
@@ -374,8 +381,12 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const i64 e = (i64)tile_off[g] + (i64)(tty - (bx.y >> 4)) * ntx + (ttx - (bx.x >> 4));
       float* out = partial + e * kGradVals;
 #pragma unroll
-      for (int v = 0; v < kGradVals; ++v)
-        out[v] = ((s_part[j][0][v] + s_part[j][1][v]) + s_part[j][2][v]) + s_part[j][3][v];
+      for (int v = 0; v < kGradVals; ++v) {
+        float acc = s_part[j][0][v];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) acc += s_part[j][r][v];
+        out[v] = acc;
+      }
     }
   }
 }

@@ -250,3 +250,49 @@ def test_depth_chunked_scan_with_carry_equals_single_pass(device):
     want = co.cumprod_forward_f64(p.x, p.inv)
     assert_parity(ya, full[A].cpu(), want[first], "chunk A")
     assert_parity(yb, full[B].cpu(), want[~first], "chunk B with carry")
+
+
+def test_check_groups(device):
+    gc, co = _mods()
+    key = make_keys(50000, "poisson8", 2)
+    inv, inv_len = co.groups_from_key(key)
+    assert gc.check_groups(inv.to(device), inv_len.to(device)) == 0
+    bad_len = inv_len.clone()
+    bad_len[3] += 1
+    assert gc.check_groups(inv.to(device), bad_len.to(device)) > 0
+    bad_inv = inv.clone()
+    bad_inv[100:] += 1  # a skipped group id
+    assert gc.check_groups(bad_inv.to(device), inv_len.to(device)) > 0
+
+
+def test_hip_graph_capture_and_replay(device):
+    """The launch path allocates nothing and never synchronises (workspace is reused), so forward + backward
+    can be captured into a HIP graph and replayed on new data."""
+    gc, co = _mods()
+    n = 500_000
+    key = make_keys(n, "mixed", 8)
+    inv, inv_len = co.groups_from_key(key)
+    x = make_values(n, 8).to(device)
+    go = make_values(n, 9, "normal").to(device)
+    invd, ild = inv.to(device), inv_len.to(device)
+    y, g = torch.empty_like(x), torch.empty_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):  # warm-up on the capture stream: workspace gets allocated here
+            gc.grouped_cumprod_forward(x, invd, y)
+            gc.grouped_cumprod_backward(x, y, go, invd, g, ild)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        gc.grouped_cumprod_forward(x, invd, y)
+        gc.grouped_cumprod_backward(x, y, go, invd, g, ild)
+    x2 = make_values(n, 10)
+    x.copy_(x2.to(device))  # new inputs in the captured buffers
+    y.zero_(); g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    want_y = co.cumprod_forward(x2, key)
+    assert_parity(y, want_y, want_y, "graph replay forward")
+    scale = co.cumprod_backward_f64(x2, want_y, go.cpu().abs(), inv)
+    assert_parity(g, co.cumprod_backward_f64(x2, want_y, go.cpu(), inv).float(), scale, "graph replay backward")

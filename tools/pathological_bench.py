@@ -1,0 +1,49 @@
+"""Worst-case inputs for the scan: groups far longer than the look-back window (fallback kernel active)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import grouped_cumprod as gc  # noqa: E402
+
+
+def timeit(fn, iters=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    n = 166_000_000
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = 1.0 - 1e-3 * torch.rand(n, device=dev, generator=g)
+    go = torch.randn(n, device=dev, generator=g)
+    y, gi = torch.empty_like(x), torch.empty_like(x)
+    cases = {}
+    cases["one group = whole array"] = torch.zeros(n, dtype=torch.int32, device=dev)
+    for lo, hi in ((5000, 13000), (20000, 60000), (300000, 900000)):
+        lens = torch.randint(lo, hi, (n // lo + 2,), device=dev, generator=g)
+        ids = torch.arange(lens.numel(), device=dev, dtype=torch.int32)
+        cases[f"groups of {lo}-{hi}"] = torch.repeat_interleave(ids, lens)[:n].contiguous()
+    lens = torch.full((n // 80 + 2,), 80, device=dev)
+    cases["groups of 80 (reference point)"] = torch.repeat_interleave(torch.arange(lens.numel(), device=dev, dtype=torch.int32), lens)[:n].contiguous()
+    for name, key in cases.items():
+        inv_len = torch.zeros(1, dtype=torch.int32, device=dev)
+        tf = timeit(lambda: gc.grouped_cumprod_forward(x, key, y))
+        fb = gc.last_fallback_tiles(dev)
+        tb = timeit(lambda: gc.grouped_cumprod_backward(x, y, go, key, gi, inv_len))
+        print(f"{name:32s} fwd {tf*1e3:8.1f} us ({12*n/tf/1e6:6.0f} GB/s)  bwd {tb*1e3:8.1f} us ({20*n/tb/1e6:6.0f} GB/s)  fallback tiles {fb}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

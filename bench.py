@@ -59,6 +59,48 @@ def cpu_baseline(p, sample_pairs):
     }
 
 
+def function_level(dev, workload):
+    """Rows f1/f2 (outside the timed region, informational): the whole rasterise-and-blend Function of the
+    reference (gs_model.py:666-692, :786-820) on a scene of the same shape — tile binning, fused blend
+    forward, fused blend backward — in splat-pixel pairs per second."""
+    import torch
+
+    from simplegaussiansplat_tk71_amd import raster, synthetic
+
+    if workload not in synthetic.CONFIGS:
+        return None
+    sc = synthetic.make_scene_config(workload, seed=0, device=dev)
+    w, h = sc["width"], sc["height"]
+    pairs = int(sc["boxsize"].sum().item())
+    params = (sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"])
+
+    def timed(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            r = fn()
+        b.record()
+        torch.cuda.synchronize()
+        return r, a.elapsed_time(b) / iters
+
+    bins, t_bin = timed(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h))
+    img, t_fwd = timed(lambda: raster.blend_forward(bins, *params))
+    gimg = torch.randn_like(img)
+    _, t_bwd = timed(lambda: raster.blend_backward(bins, *params, img, gimg))
+    return {
+        "what": "custom_autograd_grouped_cumprod: tile binning + fused blend forward + backward (no pair list materialised)",
+        "gaussians": int(sc["start"].size(0)),
+        "pairs": pairs,
+        "tile_pairs": bins.n_tile_pairs,
+        "bin_ms": t_bin,
+        "forward_ms": t_fwd,
+        "backward_ms": t_bwd,
+        "pairs_per_s": pairs / ((t_bin + t_fwd + t_bwd) * 1e-3),
+    }
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -232,6 +274,8 @@ def main():
                 "fwd_plus_bwd_frac": (BYTES_FWD + BYTES_BWD) * m / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS,
             },
         }
+        if world == 1:
+            out["function_level"] = function_level(dev, args.workload)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, args.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -85,3 +85,33 @@ def test_cpu_tensors_are_rejected():
         gc.grouped_cumprod_forward(x, k, x.clone())
     with pytest.raises(RuntimeError, match="scalar type"):
         gc.grouped_cumprod_forward(x, k.long(), x.clone())
+
+
+def test_raster_argument_validation_needs_no_gpu():
+    import ctypes
+
+    from simplegaussiansplat_tk71_amd import _lib
+
+    lib = _lib.load()
+    tx, ty = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert lib.gcp_tile_grid(1919, 1079, ctypes.byref(tx), ctypes.byref(ty)) == 0
+    assert (tx.value, ty.value) == (120, 68)  # (1919+1)/16, ceil((1079+1)/16)
+    assert lib.gcp_tile_grid(-1, 5, ctypes.byref(tx), ctypes.byref(ty)) == 1
+    assert lib.gcp_bin_workspace_bytes(1000, 3000) % 256 == 0
+    assert lib.gcp_bin_workspace_bytes(1_000_000, 3_000_000) < 64 << 20
+    assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4  # 9 floats per (tile, Gaussian) entry
+    k = ctypes.c_int64(-1)
+    assert lib.gcp_bin_tiles_count(None, None, -1, 10, 10, None, ctypes.byref(k), None, 0, None) == 1
+    assert lib.gcp_blend_forward(None, None, None, None, None, None, 5, 10, 10, None, None, None, None) == 1
+    assert lib.gcp_exclusive_scan_i32(None, None, 5, None, 0, None) == 1
+
+
+def test_raster_rejects_cpu_tensors():
+    import pytest
+    import torch
+
+    from simplegaussiansplat_tk71_amd import raster
+
+    z = torch.zeros(3, 2, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        raster.bin_tiles(z, z, 16, 16)

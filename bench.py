@@ -202,7 +202,7 @@ def main():
 
     # frame assembly / gradient distribution (outside the timed region; the scan path has no collective)
     gather_ms = scatter_ms = None
-    if world > 1:
+    if world > 1 and os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1":
         try:
             from simplegaussiansplat_tk71_amd import sharding
 

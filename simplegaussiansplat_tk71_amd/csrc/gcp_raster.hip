@@ -18,9 +18,12 @@
 //       no atomics, deterministic.  A wave skips an entry when no lane is inside its box.
 //       Backward walks FORWARD too: the exclusive suffix sum of (dL/dI . p) the reference gets
 //       from a flipped grouped cumsum (gs_model.py:716-722) equals (dL/dI . I) - inclusive
-//       prefix, and I is the saved forward image.  Per-pair gradients are summed over the
-//       tile's pixels by DPP wave reductions into one slot per (tile, Gaussian) entry
-//       (Gaussian-major order), and a last kernel sums each Gaussian's few slots.
+//       prefix, and I is the saved forward image.  Per-pair gradients collapse to 7 per-lane values;
+//       they are summed along each pixel row of the tile (16 lanes = one DPP row, 4 fused
+//       v_add_f32_dpp) into LDS, one thread per entry folds the 16 rows (dy is constant along a
+//       row) into the entry's slot in Gaussian-major order, and a last kernel sums each Gaussian's
+//       few slots.  (An entry-parallel variant with the pair values parked in LDS was measured
+//       slower, 1.88 vs 1.69 ms: it cannot skip the waves an entry does not touch.)
 //       No float atomics anywhere => bitwise reproducible.
 //   The per-pixel CSR (pixel offsets, pair->Gaussian, pair->rect index) that the scan API
 //   consumes is exported by the same traversal (k_pixel_count / k_pixel_fill): bit-exact with
@@ -42,7 +45,8 @@ using namespace gcp;
 constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
 constexpr int kStageBwd = 32;       // (backward; LDS also holds the per-pixel-row partial sums)
-constexpr int kGradVals = 9;        // go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
+constexpr int kGradVals = 9;        // per (tile, Gaussian) slot: go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
+constexpr int kRowVals = 7;         // per pixel row in LDS: go, gl0..2, S(c), S(c dx), S(c dx dx)   (dy is constant along a row)
 constexpr int kSortChunk = 2048;    // keys per radix block
 constexpr int kScanChunk = 2048;    // ints per prefix-sum block
 
@@ -53,6 +57,20 @@ __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_f<0x114, 0xf>(0.0f, v);
   v += dpp_f<0x118, 0xf>(0.0f, v);
   return v;
+}
+
+// exp(x) as exp2 of a compensated product: y = x*log2(e) is formed as hi + lo (fma residual + the
+// low word of log2(e)), v_exp_f32 takes the high part and the low part enters as a first-order
+// correction.  ~1 ulp like libm's expf, 6 VALU instead of 13 (no range reduction / ldexp / special
+// casing: overflow gives inf, underflow 0 on its own).  Tiny results (< 2^-126) flush to 0, which
+// only ever multiplies an opacity.
+__device__ __forceinline__ float exp_fast_accurate(float x) {
+  const float kL2eHi = 1.44269502e+00f, kL2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
+  const float yh = x * kL2eHi;
+  float yl = __builtin_fmaf(x, kL2eHi, -yh);
+  yl = __builtin_fmaf(x, kL2eLo, yl);
+  const float e = __builtin_amdgcn_exp2f(yh);
+  return __builtin_fmaf(e, yl * kLn2, e);
 }
 
 struct TileGrid { int tx, ty; };
@@ -240,7 +258,7 @@ struct BlendArgs {
 
 template <int STAGE>
 struct Staged {
-  int4 box[STAGE];
+  int4 box[STAGE];     // x0, y0, x1-x0, y1-y0 (clamped to the image)
   float4 geo[STAGE];   // mx, my, opacity, 1/opacity (0 if opacity == 0)
   float4 vin[STAGE];   // a b c d  (Λ = [[a,b],[c,d]])
   float4 col[STAGE];   // l0 l1 l2 -
@@ -252,7 +270,7 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     const i64 g = a.tile_list[first + j];
     Box b;
     load_box(a.start, a.end, g, a.W, a.H, b);
-    s.box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
+    s.box[j] = make_int4(b.x0, b.y0, b.x1 - b.x0, b.y1 - b.y0);  // origin + extent: one unsigned compare per axis
     const float op = a.opacity[g];
     s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], op, op != 0.0f ? 1.0f / op : 0.0f);
     s.vin[j] = make_float4(a.vinv[4 * g], a.vinv[4 * g + 1], a.vinv[4 * g + 2], a.vinv[4 * g + 3]);
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
     __syncthreads();
     for (int k = 0; k < cnt; ++k) {
       const int4 bx = s.box[k];
-      const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+      const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) continue;
       if (in) {
         const float4 ge = s.geo[k];
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
         // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
         const float t0 = dx * vi.x + dy * vi.z;
         const float t1 = dx * vi.y + dy * vi.w;
-        const float g = expf(-0.5f * (t0 * dx + t1 * dy));
+        const float g = exp_fast_accurate(-0.5f * (t0 * dx + t1 * dy));
         const float anti = 1.0f - ge.z * g;             // gs_model.py:535
         const float incl = T * anti;                    // inclusive grouped cumprod
         if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
                                                    const float* __restrict__ grad_image,
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   __shared__ Staged<kStageBwd> s;
-  __shared__ float s_part[kStageBwd][16][kGradVals];  // [entry][pixel row of the tile][value]
+  __shared__ float s_part[kStageBwd][16][kRowVals];  // [entry][pixel row of the tile][value]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tile = blockIdx.x;
   const int ttx = tile % a.tiles_x, tty = tile / a.tiles_x;
@@ -331,13 +349,12 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     __syncthreads();
     for (int k = 0; k < cnt; ++k) {
       const int4 bx = s.box[k];
-      const bool in = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+      const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) {
-        if (lane < 4 * kGradVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
+        if (lane < 4 * kRowVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
         continue;
       }
-      float r_o = 0.0f, r_l0 = 0.0f, r_l1 = 0.0f, r_l2 = 0.0f, r_cx = 0.0f, r_cy = 0.0f, r_xx = 0.0f, r_xy = 0.0f,
-            r_yy = 0.0f;
+      float r_o = 0.0f, r_l0 = 0.0f, r_l1 = 0.0f, r_l2 = 0.0f, r_c = 0.0f, r_cx = 0.0f, r_xx = 0.0f;
       if (in) {
         const float4 ge = s.geo[k];
         const float4 vi = s.vin[k];
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         const float dx = fx - ge.x, dy = fy - ge.y;
         const float t0 = dx * vi.x + dy * vi.z;
         const float t1 = dx * vi.y + dy * vi.w;
-        const float g = expf(-0.5f * (t0 * dx + t1 * dy));
+        const float g = exp_fast_accurate(-0.5f * (t0 * dx + t1 * dy));
         const float op = ge.z;
         const float anti = 1.0f - op * g;
         const float incl = T * anti;
@@ -358,18 +375,16 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
           r_o = -(g * sa) + gp * ge.w;                              // gs_model.py:733-740 (gp / o, o != 0)
           r_l0 = g0 * wgt; r_l1 = g1 * wgt; r_l2 = g2 * wgt;        // true dL/dl (reference: gp / l, Q2)
           const float common = gp - (op * g) * sa;                  // gs_model.py:747-748, :757-758
-          r_cx = common * dx; r_cy = common * dy;
-          r_xx = common * dx * dx; r_xy = common * dx * dy; r_yy = common * dy * dy;
+          r_c = common; r_cx = common * dx; r_xx = r_cx * dx;
         }
         T = incl;
       }
       r_o = row_sum16(r_o);
       r_l0 = row_sum16(r_l0); r_l1 = row_sum16(r_l1); r_l2 = row_sum16(r_l2);
-      r_cx = row_sum16(r_cx); r_cy = row_sum16(r_cy);
-      r_xx = row_sum16(r_xx); r_xy = row_sum16(r_xy); r_yy = row_sum16(r_yy);
+      r_c = row_sum16(r_c); r_cx = row_sum16(r_cx); r_xx = row_sum16(r_xx);
       if ((lane & 15) == 15) {
         float* d = s_part[k][w * 4 + (lane >> 4)];
-        d[0] = r_o; d[1] = r_l0; d[2] = r_l1; d[3] = r_l2; d[4] = r_cx; d[5] = r_cy; d[6] = r_xx; d[7] = r_xy; d[8] = r_yy;
+        d[0] = r_o; d[1] = r_l0; d[2] = r_l1; d[3] = r_l2; d[4] = r_c; d[5] = r_cx; d[6] = r_xx;
       }
     }
     __syncthreads();
@@ -377,16 +392,20 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     for (int j = threadIdx.x; j < cnt; j += 256) {
       const i64 g = a.tile_list[base + j];
       const int4 bx = s.box[j];
-      const int ntx = (bx.z >> 4) - (bx.x >> 4) + 1;
+      const int ntx = ((bx.x + bx.z) >> 4) - (bx.x >> 4) + 1;
       const i64 e = (i64)tile_off[g] + (i64)(tty - (bx.y >> 4)) * ntx + (ttx - (bx.x >> 4));
       float* out = partial + e * kGradVals;
+      const float my = s.geo[j].y;
+      float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f, cx = 0.0f, cy = 0.0f, xx = 0.0f, xy = 0.0f, yy = 0.0f;
 #pragma unroll
-      for (int v = 0; v < kGradVals; ++v) {
-        float acc = s_part[j][0][v];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) acc += s_part[j][r][v];
-        out[v] = acc;
+      for (int r = 0; r < 16; ++r) {
+        const float* d = s_part[j][r];
+        const float dy = (float)(tty * kTile + r) - my;  // constant along the pixel row
+        o0 += d[0]; o1 += d[1]; o2 += d[2]; o3 += d[3];
+        cx += d[5]; cy += dy * d[4];
+        xx += d[6]; xy += dy * d[5]; yy += dy * dy * d[4];
       }
+      out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = cx; out[5] = cy; out[6] = xx; out[7] = xy; out[8] = yy;
     }
   }
 }

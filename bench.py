@@ -48,6 +48,14 @@ def cpu_baseline(p, sample_pairs):
     t1 = time.perf_counter()
     co.cumprod_backward(x, y, go, inv, il)
     t2 = time.perf_counter()
+    # the "pure-PyTorch torch.cumprod path" of BASELINE.json (per-group torch.cumprod), forward only, smaller sample
+    from oracle import torch_path as tp
+
+    g8 = int(torch.searchsorted(inv_len, torch.tensor(min(8_000_000, s), dtype=inv_len.dtype)).item())
+    s8 = int(inv_len[max(g8, 1) - 1].item())
+    t3 = time.perf_counter()
+    tp.grouped_cumprod(x[:s8].contiguous(), key[:s8].contiguous())
+    t4 = time.perf_counter()
     return {
         "value": s / (t2 - t0),
         "unit": "pairs/s",
@@ -56,6 +64,8 @@ def cpu_baseline(p, sample_pairs):
         "sample": f"first {g} pixel groups = {s} pairs of the same pair list; oracle/gcp_oracle.c "
         f"(sequential fp32, literal O(L^2) backward loop of the reference); fwd {1e3*(t1-t0):.1f} ms, "
         f"bwd {1e3*(t2-t1):.1f} ms; host has {os.cpu_count()} cpus",
+        "torch_cumprod_path_forward": {"value": s8 / (t4 - t3), "unit": "pairs/s", "threads": torch.get_num_threads(),
+                                       "sample": f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"},
     }
 
 

@@ -59,7 +59,7 @@ def _workspace(device, stream_handle, n):
     key = (device.index, stream_handle)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
-        # torch.zeros: the control words must start at zero (gcp_workspace_init contract)
+        # tile descriptors + an introspection counter; stateless, zeroed only so the counter reads 0 before use
         ws = torch.zeros(max(need + need // 2, 1 << 16), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws

@@ -39,6 +39,12 @@ def test_partition_is_balanced_and_on_group_boundaries():
                 assert int(inv.min()) == 0 and int(inv.max()) == s.n_groups - 1 and int(inv_len[-1]) == s.n_pairs
 
 
+def test_shards_from_counts():
+    sh = sharding.shards_from_counts([3, 0, 5], [30, 0, 42])
+    assert [(s.group_start, s.group_end, s.pair_start, s.pair_end) for s in sh] == [(0, 3, 0, 30), (3, 3, 30, 30), (3, 8, 30, 72)]
+    assert [s.rank for s in sh] == [0, 1, 2]
+
+
 def test_partition_degenerate():
     one = torch.tensor([10], dtype=torch.int32)
     shards = sharding.partition_groups(one, 4)

@@ -30,7 +30,8 @@ def short(kernel):
 
 def pmc(dirname, counter):
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun MERGES into gpurun_out/: only the newest run counts
         for r in csv.DictReader(open(f)):
             s = short(r["Kernel_Name"])
             if s and r["Counter_Name"] == counter:
@@ -42,7 +43,7 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    stats = max(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
     ours = [r for r in rows if "gcp_" in r["Name"]]
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:

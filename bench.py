@@ -133,12 +133,24 @@ def main():
     import torch
     import torch.distributed as dist
 
-    import grouped_cumprod as gc
-    from simplegaussiansplat_tk71_amd import synthetic
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # the HIP library is prebuilt in-tree; if it is missing, local rank 0 builds it and the others wait
+    from simplegaussiansplat_tk71_amd import _build
+
+    if not os.path.exists(_build.LIB_PATH):
+        if local_rank == 0:
+            _build.build_hip_library(force=True)
+        else:
+            t_wait = time.time()
+            while not os.path.exists(_build.LIB_PATH) and time.time() - t_wait < 300:
+                time.sleep(1.0)
+            time.sleep(2.0)  # let the linker finish writing
+    import grouped_cumprod as gc
+    from simplegaussiansplat_tk71_amd import synthetic
+
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit(

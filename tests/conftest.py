@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The HIP library is built in-tree and normally travels with the checkout; build it if it is not there
+    (hipcc cross-compiles without a GPU).  Tests never fall back to anything else."""
+    from simplegaussiansplat_tk71_amd import _build
+
+    if not os.path.exists(_build.LIB_PATH):
+        _build.build_hip_library(force=True)
+
+
 @pytest.fixture(scope="session")
 def device():
     import torch

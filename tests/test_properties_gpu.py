@@ -1,0 +1,87 @@
+"""Size-independent properties of the scans (no oracle needed), on hypothesis-generated run structures and
+at BASELINE.json's full size."""
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _keys_from_lens(lens, device):
+    lens = torch.tensor(lens, dtype=torch.long)
+    ids = torch.arange(lens.numel())
+    vals = ((ids * 7919) % 1000 + (ids % 2) * 1000003).to(torch.int32)
+    return torch.repeat_interleave(vals, lens).to(device)
+
+
+# run lengths that straddle the kernel's structural sizes: 4-element lanes, 256-element rows, 1024 per
+# wave, 4096 per tile / look-back window
+_len = st.one_of(st.integers(1, 12), st.integers(250, 262), st.integers(1020, 1030), st.integers(4090, 4102),
+                 st.integers(8190, 8200), st.integers(1, 20000))
+
+
+def _check_properties(gc, x, z, key):
+    n = x.numel()
+    dev = x.device
+    out = lambda: torch.empty(n, device=dev)  # noqa: E731
+    fx, fz, fxz = out(), out(), out()
+    # cumsum is linear
+    gc.grouped_cumsum_forward(x, key, fx)
+    gc.grouped_cumsum_forward(z, key, fz)
+    gc.grouped_cumsum_forward((2.0 * x - 3.0 * z).contiguous(), key, fxz)
+    ax, az = out(), out()
+    gc.grouped_cumsum_forward(x.abs(), key, ax)
+    gc.grouped_cumsum_forward(z.abs(), key, az)
+    scale = 2.0 * ax + 3.0 * az
+    assert bool(((fxz - (2.0 * fx - 3.0 * fz)).abs() <= 4 * TOL * (1 + scale)).all())
+    # prefix + suffix - self = group total: constant inside a group, so its own grouped max == min
+    rx = out()
+    gc.grouped_cumsum_reverse(x, key, rx)
+    total = fx + rx - x
+    head = torch.ones(n, dtype=torch.bool, device=dev)
+    head[1:] = key[1:] != key[:-1]
+    gid = torch.cumsum(head.long(), 0) - 1
+    ng = int(gid[-1]) + 1
+    ref_total = torch.zeros(ng, device=dev, dtype=torch.float64).index_add_(0, gid, x.double())
+    abs_total = torch.zeros(ng, device=dev, dtype=torch.float64).index_add_(0, gid, x.double().abs())
+    assert bool(((total.double() - ref_total[gid]).abs() <= 4 * TOL * (1 + abs_total[gid])).all())
+    # cumprod is a homomorphism for the elementwise product
+    px, pz, pxz = out(), out(), out()
+    u, v = 1.0 - 0.5 * torch.rand_like(x), 1.0 - 0.5 * torch.rand_like(x)
+    gc.grouped_cumprod_forward(u, key, px)
+    gc.grouped_cumprod_forward(v, key, pz)
+    gc.grouped_cumprod_forward((u * v).contiguous(), key, pxz)
+    assert torch.allclose(pxz, px * pz, atol=TOL, rtol=1e-3)
+    # backward with grad_out = 1 and param_cumprod = 1, param = 1 is the remaining length (exact)
+    ones = torch.ones(n, device=dev)
+    rem = out()
+    gc.grouped_cumprod_backward(ones, ones, ones, key, rem, torch.zeros(1, dtype=torch.int32, device=dev))
+    cnt = out()
+    gc.grouped_cumsum_reverse(ones, key, cnt)
+    assert torch.equal(rem, cnt)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(lens=st.lists(_len, min_size=1, max_size=12), seed=st.integers(0, 2**16))
+def test_scan_properties_random_structures(device, lens, seed):
+    import grouped_cumprod as gc
+
+    key = _keys_from_lens(lens, device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(key.numel(), device=device, generator=g)
+    z = torch.randn(key.numel(), device=device, generator=g)
+    _check_properties(gc, x, z, key)
+
+
+def test_scan_properties_full_size_cfg3(device):
+    """The same properties on BASELINE.json's metric configuration (M ~ 1.66e8 pairs)."""
+    import grouped_cumprod as gc
+    from simplegaussiansplat_tk71_amd import synthetic
+
+    p = synthetic.make_config("cfg3", seed=2, device=device)
+    g = torch.Generator(device=device).manual_seed(5)
+    x = torch.randn(p.n_pairs, device=device, generator=g)
+    z = torch.randn(p.n_pairs, device=device, generator=g)
+    _check_properties(gc, x, z, p.key)

@@ -137,3 +137,78 @@ def groups_from_frame(frame: torch.Tensor, group_key: torch.Tensor) -> torch.Ten
     """Inverse gather: dL/dI at every group's pixel (gs_model.py:703-706)."""
     k = group_key.long()
     return frame[k // 10000, k % 10000]
+
+
+# ---------------------------------------------------------------------------------------------
+# Function-level sharding (row f1): image row bands
+# ---------------------------------------------------------------------------------------------
+def row_bands(height: int, world_size: int, tile: int = 16) -> List[tuple]:
+    """Split image rows 0..height (inclusive, the reference's (H+1)-row image, gs_model.py:505) into
+    `world_size` contiguous bands [y0, y1] whose starts are multiples of the 16-pixel tile, so a band's
+    tiles are whole tiles of the full frame.  Bands may be empty (y1 < y0) when there are more ranks than
+    tile rows."""
+    n_tile_rows = (height + 1 + tile - 1) // tile
+    bands = []
+    for r in range(world_size):
+        t0 = (n_tile_rows * r) // world_size
+        t1 = (n_tile_rows * (r + 1)) // world_size
+        y0, y1 = t0 * tile, min(t1 * tile - 1, height)
+        bands.append((y0, y1))
+    return bands
+
+
+def band_view(startpoint: torch.Tensor, endpoint: torch.Tensor, mean: torch.Tensor, band: tuple):
+    """Inputs of the blend for one band: y coordinates shifted so the band starts at row 0 and boxes cut
+    to the band (a box that misses the band becomes empty and is skipped by the kernels; depth order is
+    untouched, so per-pixel results are exactly those of the full frame).  Returns
+    (startpoint', endpoint', mean', band_height) with band_height = y1 - y0 (the `image_height` argument)."""
+    y0, y1 = band
+    shift = torch.tensor([0, y0], dtype=startpoint.dtype, device=startpoint.device)
+    s = startpoint - shift
+    e = endpoint - shift
+    s = torch.stack([s[:, 0], s[:, 1].clamp(min=0)], 1)
+    e = torch.stack([e[:, 0], e[:, 1].clamp(max=y1 - y0)], 1)
+    m = mean - shift.to(mean.dtype)
+    return s, e, m, y1 - y0
+
+
+def gather_bands(band_image: torch.Tensor, bands: Sequence[tuple], dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """ONE gather of row bands [(y1-y0+1), W+1, C] into the frame [(H+1), W+1, C] on `dst`."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = max(max(b[1] - b[0] + 1, 0) for b in bands)
+    send = _padded(band_image, rows)
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst, group=group)
+        return torch.cat([bufs[r][: max(bands[r][1] - bands[r][0] + 1, 0)] for r in range(world)], 0)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def scatter_bands(frame: Optional[torch.Tensor], bands: Sequence[tuple], like: torch.Tensor, src: int = 0, group=None):
+    """ONE scatter of dL/dI row bands from `src` to their owners (`like`: this rank's band image)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rows = max(max(b[1] - b[0] + 1, 0) for b in bands)
+    recv = like.new_empty((rows,) + tuple(like.shape[1:]))
+    if rank == src:
+        parts = [_padded(frame[b[0] : b[1] + 1], rows) for b in bands]
+        dist.scatter(recv, parts, src=src, group=group)
+    else:
+        dist.scatter(recv, None, src=src, group=group)
+    y0, y1 = bands[rank]
+    return recv[: max(y1 - y0 + 1, 0)]
+
+
+def allreduce_gaussian_grads(*grads: torch.Tensor, group=None):
+    """Per-Gaussian gradients are sums over pixels; a box that straddles bands has a share on several ranks.
+    ONE all-reduce of the concatenated N x (2 + 4 + 1 + 3) floats (reduce-scatter + all-gather over xGMI)."""
+    flat = torch.cat([g.reshape(g.size(0), -1) for g in grads], 1).contiguous()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, c = [], 0
+    for g in grads:
+        k = g[0].numel() if g.size(0) else 0
+        out.append(flat[:, c : c + k].reshape(g.shape))
+        c += k
+    return out

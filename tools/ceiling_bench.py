@@ -16,7 +16,13 @@ V = ctypes.c_void_p
 
 def main():
     dev = torch.device("cuda", 0)
-    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libstream_ceiling.so"))
+    so = os.path.join(ROOT, "tools", "libstream_ceiling.so")
+    if not os.path.exists(so):
+        import subprocess
+
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so,
+                        os.path.join(ROOT, "tools", "stream_ceiling.hip")], check=True)
+    lib = ctypes.CDLL(so)
     lib.ceiling12.argtypes = [V, V, V, ctypes.c_longlong, ctypes.c_int, V]
     lib.ceiling20.argtypes = [V, V, V, V, V, ctypes.c_longlong, ctypes.c_int, V]
     p = synthetic.make_config("cfg3", seed=0, device=dev)

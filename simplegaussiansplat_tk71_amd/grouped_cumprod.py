@@ -54,25 +54,28 @@ def _check_tensor(t, name, dtype, device, numel=None):
 
 
 def _workspace(device, stream_handle, n):
-    lib = _lib.load()
-    need = lib.gcp_workspace_bytes(n)
+    """Scratch of the current (device, stream): reused across calls, grown geometrically."""
     key = (device.index, stream_handle)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        # tile descriptors + an introspection counter; stateless, zeroed only so the counter reads 0 before use
-        ws = torch.zeros(max(need + need // 2, 1 << 16), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    hit = _workspaces.get(key)
+    if hit is not None and hit[1] >= n:
+        return hit[0]
+    need = _lib.load().gcp_workspace_bytes(n + n // 2)
+    # tile descriptors + an introspection counter; stateless, zeroed only so the counter reads 0 before use
+    ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
+    _workspaces[key] = (ws, n + n // 2)
     return ws
 
 
 def _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n=()):
     lib = _lib.load()
-    with torch.cuda.device(device):
-        stream = torch.cuda.current_stream(device).cuda_stream
-        ws = _workspace(device, stream, n)
-        fn = getattr(lib, fn_name)
-        status = fn(*ptrs_before_n, n, *ptrs_after_n, ws.data_ptr(), ws.numel(), stream)
-    _lib.check(status, fn_name)
+    if device.index != torch.cuda.current_device():
+        with torch.cuda.device(device):
+            return _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    ws = _workspace(device, stream, n)
+    status = getattr(lib, fn_name)(*ptrs_before_n, n, *ptrs_after_n, ws.data_ptr(), ws.numel(), stream)
+    if status:
+        _lib.check(status, fn_name)
 
 
 def _forward(fn_name, x, key, y):
@@ -187,10 +190,10 @@ def last_fallback_tiles(device=None):
     out = ctypes.c_int64(0)
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
-        ws = _workspaces.get((device.index, stream))
-        if ws is None:
+        hit = _workspaces.get((device.index, stream))
+        if hit is None:
             return 0
-        status = lib.gcp_last_fallback_tiles(ws.data_ptr(), stream, ctypes.byref(out))
+        status = lib.gcp_last_fallback_tiles(hit[0].data_ptr(), stream, ctypes.byref(out))
     _lib.check(status, "gcp_last_fallback_tiles")
     return out.value
 

@@ -296,3 +296,36 @@ def test_hip_graph_capture_and_replay(device):
     assert_parity(y, want_y, want_y, "graph replay forward")
     scale = co.cumprod_backward_f64(x2, want_y, go.cpu().abs(), inv)
     assert_parity(g, co.cumprod_backward_f64(x2, want_y, go.cpu(), inv).float(), scale, "graph replay backward")
+
+
+def test_more_than_2_31_elements(device):
+    """Maximum sizes: the reference takes n as `int` (grouped_cumprod_backward.cu:52); here every array index is
+    64-bit.  n = 2^31 + 12296 elements (8.6 GB per array), groups of 1000, exact integer results."""
+    import grouped_cumprod as gc
+
+    free, _ = torch.cuda.mem_get_info(device)
+    n = (1 << 31) + 3 * 4097 + 5
+    if free < 6 * 4 * n:
+        pytest.skip("not enough free HBM for a > 2^31-element case")
+    L = 1000
+    ngroups = (n + L - 1) // L
+    key = torch.arange(ngroups, dtype=torch.int32, device=device).repeat_interleave(L)[:n].contiguous()
+    pos = torch.arange(1, L + 1, dtype=torch.float32, device=device).repeat(ngroups)[:n].contiguous()
+    ones = torch.ones(n, device=device)
+    out = torch.empty(n, device=device)
+    gc.grouped_cumsum_forward(ones, key, out)
+    assert torch.equal(out, pos)
+    tail = n - (ngroups - 1) * L  # length of the last (partial) group
+    gc.grouped_cumprod_backward(ones, ones, ones, key, out, torch.zeros(1, dtype=torch.int32, device=device))
+    # remaining length inside the group: L + 1 - pos, except in the last group
+    want = (L + 1) - pos
+    want[(ngroups - 1) * L :] = torch.arange(tail, 0, -1, dtype=torch.float32, device=device)
+    assert torch.equal(out, want)
+    del pos, want
+    half = torch.full((n,), 0.5, device=device)
+    gc.grouped_cumprod_forward(half, key, out)
+    # spot-check both ends and the 2^31 crossing: 0.5^k is exact (denormals included) down to 2^-149
+    table = torch.pow(torch.tensor(0.5, dtype=torch.float64), torch.arange(0, L + 1, dtype=torch.float64)).float().to(device)
+    for lo in (0, (1 << 31) - 3000, n - 3000):
+        idx = torch.arange(lo, lo + 3000, device=device)
+        assert torch.equal(out[idx], table[(idx % L) + 1])

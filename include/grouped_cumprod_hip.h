@@ -218,6 +218,7 @@ int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t
                          int32_t width, int32_t height, const int32_t* tile_start,
                          const int32_t* tile_list, const int32_t* pixel_off,
                          const int32_t* box_off, int32_t* pair_gauss, int32_t* pair_index,
+                         int32_t* pair_key /* optional: y*10000+x of every pair, may be NULL */,
                          void* stream);
 
 #ifdef __cplusplus

@@ -442,7 +442,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __restrict__ pixel_count,
                                                      const int* __restrict__ pixel_off,
                                                      const int* __restrict__ box_off, int* __restrict__ pair_gauss,
-                                                     int* __restrict__ pair_index) {
+                                                     int* __restrict__ pair_index, int* __restrict__ pair_key) {
   __shared__ int4 s_box[kStage];
   __shared__ int s_g[kStage];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __r
           // position of this pixel in the Gaussian-major rect list (uitility.py:336-366):
           // row-major inside the box, boxes concatenated in depth order
           pair_index[o + n] = box_off[g] + (py - bx.y) * (bx.z - bx.x + 1) + (px - bx.x);
+          if (pair_key) pair_key[o + n] = py * 10000 + px;  // the reference's pixel key (gs_model.py:538-541)
         }
         ++n;
       }
@@ -670,7 +671,7 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
   if (n_gauss > 0 && (!start_xy || !end_xy)) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
   hipLaunchKernelGGL((k_pixel_lists<false>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, pixel_count,
-                     (const int*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+                     (const int*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
   if (n_gauss > 0) {
     hipLaunchKernelGGL(k_box_sizes, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
@@ -683,7 +684,7 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
 int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
                          int32_t height, const int32_t* tile_start, const int32_t* tile_list,
                          const int32_t* pixel_off, const int32_t* box_off, int32_t* pair_gauss,
-                         int32_t* pair_index, void* stream_) {
+                         int32_t* pair_index, int32_t* pair_key, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
@@ -692,7 +693,7 @@ int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t
   if (!start_xy || !end_xy || !pixel_off || !box_off || !pair_gauss || !pair_index) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
   hipLaunchKernelGGL((k_pixel_lists<true>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, (int*)nullptr,
-                     pixel_off, box_off, pair_gauss, pair_index);
+                     pixel_off, box_off, pair_gauss, pair_index, pair_key);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

@@ -33,6 +33,7 @@ __all__ = [
     "create_alpha_brend",
     "create_alpha_blend",
     "grad_cumsum",
+    "create_alpha_brend_boxes",
     "custom_autograd_grouped_cumprod",
 ]
 
@@ -134,6 +135,32 @@ def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None):
 
 
 create_alpha_blend = create_alpha_brend  # spelling alias
+
+
+def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, image_height, flag="cumprod"):
+    """`create_alpha_brend` for callers that still hold the boxes the rects were expanded from
+    (reference: gs_model.py:601 `_create_rects(startpoint, endpoint)` feeds :607): the sort permutation and
+    the sorted keys come from the tile binning (raster.pixel_lists — bit-identical to `torch.sort(stable)`
+    of the pixel keys) instead of a radix sort over all M pairs.  `anti_opacity` is in the reference's
+    Gaussian-major rect order; returns the same [values, mask]."""
+    with torch.no_grad():
+        bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
+        pl = _raster.pixel_lists(bins, startpoint, endpoint)
+        index = pl.pair_index.long()
+        sorted_anti_opacity = anti_opacity[index]
+        output = torch.zeros_like(sorted_anti_opacity)
+        if flag == "cumprod":
+            _ext.grouped_cumprod_forward(sorted_anti_opacity, pl.pair_key, output)
+        elif flag == "cumsum":
+            _ext.grouped_cumsum_forward(sorted_anti_opacity, pl.pair_key, output)
+        unsorted = torch.empty_like(output)
+        unsorted[index] = output
+        output, mask = _mask_zero_T(unsorted)
+        if flag == "cumprod":
+            output = output / anti_opacity[mask]
+        elif flag == "cumsum":
+            output = output - anti_opacity[mask]
+        return [output, mask]
 
 
 def grad_cumsum(rects, grad, cutting_number=None):

@@ -161,6 +161,7 @@ class PixelLists:
     pixel_off: torch.Tensor   # int32[P+1], P = (H+1)*(W+1) pixels row-major (= ascending key y*10000+x)
     pair_gauss: torch.Tensor  # int32[M] Gaussian of every pair, pixel-major, depth order inside a pixel
     pair_index: torch.Tensor  # int32[M] == `index` of torch.sort(key, stable=True) (gs_model.py:547)
+    pair_key: torch.Tensor    # int32[M] == `sorted_inv` of the same sort: y*10000+x of every pair
     box_off: torch.Tensor     # int32[N+1] first Gaussian-major pair of every Gaussian
 
 
@@ -186,10 +187,12 @@ def pixel_lists(bins, startpoint, endpoint):
         _require(m == int(box_off[-1].item()), "pixel lists: pair count mismatch between pixel- and box-major views")
         pair_gauss = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
         pair_index = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+        pair_key = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
         _lib.check(
             lib.gcp_pixel_lists_fill(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                      bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), pixel_off.data_ptr(),
-                                     box_off.data_ptr(), pair_gauss.data_ptr(), pair_index.data_ptr(), st),
+                                     box_off.data_ptr(), pair_gauss.data_ptr(), pair_index.data_ptr(),
+                                     pair_key.data_ptr(), st),
             "gcp_pixel_lists_fill",
         )
-    return PixelLists(pixel_off, pair_gauss[:m], pair_index[:m], box_off)
+    return PixelLists(pixel_off, pair_gauss[:m], pair_index[:m], pair_key[:m], box_off)

@@ -195,3 +195,26 @@ def test_band_sharded_blend_equals_full_frame(device):
     assert torch.equal(torch.cat(rows, 0), full)
     for a, b in zip(acc, gfull):
         torch.testing.assert_close(a, b, atol=2e-4, rtol=1e-4)
+
+
+def test_create_alpha_brend_from_boxes_equals_sort_route(device):
+    """a5 with the sort replaced by the tile binning: same values and mask, bit for bit, as the stable-sort route."""
+    import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(400, 90, 70, 8, 51)
+    s, e = sc["start"].to(device), sc["end"].to(device)
+    # the reference's Gaussian-major rect list (uitility.py:336-366)
+    wh = (e - s + 1).long()
+    npts = wh[:, 0] * wh[:, 1]
+    gid = torch.repeat_interleave(torch.arange(s.size(0), device=device), npts)
+    local = torch.arange(int(npts.sum()), device=device) - torch.repeat_interleave(torch.cumsum(npts, 0) - npts, npts)
+    rects = torch.stack([s[gid, 0] + local % wh[gid, 0], s[gid, 1] + local // wh[gid, 0]], 1).to(torch.int32)
+    anti = 1.0 - 0.9 * torch.rand(rects.size(0), device=device, generator=torch.Generator(device=device).manual_seed(1))
+    anti[::19] = 0.0
+    for flag in ("cumprod", "cumsum"):
+        a_vals, a_mask = ck.create_alpha_brend(rects, anti, flag)
+        b_vals, b_mask = ck.create_alpha_brend_boxes(s, e, anti, 90, 70, flag)
+        assert torch.equal(a_mask, b_mask) and torch.equal(a_vals, b_vals)
+    pl = raster.pixel_lists(raster.bin_tiles(s, e, 90, 70), s, e)
+    assert torch.equal(pl.pair_key, torch.sort(ck.unique(rects), stable=True).values)

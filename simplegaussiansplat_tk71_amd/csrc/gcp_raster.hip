@@ -9,7 +9,7 @@
 // MI355X-first restatement, same results, no M-length array at all:
 //   f2  Bin Gaussians (given in depth order) into 16x16-pixel tiles: count tiles per box, prefix
 //       sum, emit (tile, gaussian) entries Gaussian-major, STABLE LSD radix sort on the tile id
-//       (8-bit digits; ranks from wave ballots, one wave per block => deterministic), so every
+//       (8-bit digits; ranks from wave ballots, waves ordered by an LDS prefix => deterministic), so every
 //       tile's list is in depth order.  K entries (~3 per Gaussian) instead of M pairs (~166).
 //   f1  One 256-thread block per tile, one pixel per lane.  The tile's list is staged through LDS
 //       256 entries at a time; every lane walks it in depth order keeping its own transmittance
@@ -77,7 +77,7 @@ struct TileGrid { int tx, ty; };
 inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTile - 1) / kTile, (H + 1 + kTile - 1) / kTile}; }
 
 // ------------------------------------------------------------------------------------------
-// Exclusive prefix sum of int32 (out has n+1 entries, out[n] = total).  Three small launches.
+// Exclusive prefix sum of int32 (out has n+1 entries, out[n] = total).  Two small launches.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int block_excl_scan_256(int v, int* s_w, int& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -103,36 +103,24 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const int* in, int* bsum, i
   if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_bsums(int* bsum, i64 nb, int* total_out) {
-  __shared__ int s_w[16];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int carry = 0;
-  for (i64 base = 0; base < nb; base += 1024) {
-    const i64 i = base + tid;
-    const int v = (i < nb) ? bsum[i] : 0;
-    const int inc = wave_incl_scan_i(v);
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int j = 0; j < 16; ++j) { const int t = s_w[j]; if (j < w) woff += t; tot += t; }
-    if (i < nb) bsum[i] = carry + woff + inc - v;
-    carry += tot;
-    __syncthreads();
-  }
-  if (tid == 0) *total_out = carry;
-}
-
-__global__ __launch_bounds__(256) void k_scan_apply(const int* in, const int* boff, int* out, i64 n) {
+// second (last) launch: every block first reduces the block sums in front of it (<= a few thousand ints,
+// L2-resident) to get its own offset — cheaper than a third launch for the block-sum scan
+__global__ __launch_bounds__(256) void k_scan_apply(const int* in, const int* bsum, int* out, i64 n, i64 nb) {
   __shared__ int s_w[4];
+  int part = 0;
+  for (i64 j = threadIdx.x; j < (i64)blockIdx.x; j += 256) part += bsum[j];
+  int boff;
+  block_excl_scan_256(part, s_w, boff);  // boff = sum of all parts = offset of this block
   const i64 base = (i64)blockIdx.x * kScanChunk + (i64)threadIdx.x * 8;
   int v[8];
   int s = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
   int total;
-  int ex = block_excl_scan_256(s, s_w, total) + boff[blockIdx.x];
+  int ex = block_excl_scan_256(s, s_w, total) + boff;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = ex; ex += v[k]; }
+  if ((i64)blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = boff + total;
 }
 
 // host: ws needs ceil(n/2048) ints
@@ -143,8 +131,7 @@ int launch_excl_scan(const int* in, int* out, i64 n, int* ws, hipStream_t stream
   }
   const i64 nb = (n + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, stream, in, ws, n);
-  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, stream, ws, nb, out + n);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, in, (const int*)ws, out, n);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, in, (const int*)ws, out, n, nb);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
@@ -199,20 +186,41 @@ __global__ __launch_bounds__(256) void k_radix_hist(const unsigned* key, i64 K, 
   hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void k_radix_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
-                                                       unsigned* val_out, i64 K, int shift, const int* hist_excl,
-                                                       int nblk) {
-  __shared__ int off[256];
-  const int lane = threadIdx.x;
-  for (int d = lane; d < 256; d += 64) off[d] = hist_excl[(i64)d * nblk + blockIdx.x];
+// Stable scatter of one 2048-key block.  Wave w owns keys [512w, 512w+512) of the block, so a digit's keys
+// of wave w go after those of waves < w: (A) every wave counts its digits, (B) an exclusive prefix over the
+// waves plus the block's global offset gives every (wave, digit) its first slot, (C) each wave ranks its keys
+// 64 at a time in order — peers with the same digit from 8 ballots, rank = earlier lanes among the peers —
+// touching only its own LDS row, so no block barrier inside the loop.  Deterministic: no atomics decide a slot.
+__global__ __launch_bounds__(256) void k_radix_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
+                                                        unsigned* val_out, i64 K, int shift, const int* hist_excl,
+                                                        int nblk) {
+  __shared__ int off[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int d = lane; d < 256; d += 64) off[w][d] = 0;
   __syncthreads();
-  const i64 base = (i64)blockIdx.x * kSortChunk;
-  for (int step = 0; step < kSortChunk / 64; ++step) {
-    const i64 i = base + step * 64 + lane;
+  const i64 wbase = (i64)blockIdx.x * kSortChunk + (i64)w * (kSortChunk / 4);
+  constexpr int kSteps = kSortChunk / 4 / 64;
+  unsigned k[kSteps], v[kSteps];
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) {  // (A)
+    const i64 i = wbase + st * 64 + lane;
     const bool valid = i < K;
-    const unsigned k = valid ? key[i] : 0u;
-    const unsigned v = valid ? val[i] : 0u;
-    const unsigned d = (k >> shift) & 255u;
+    k[st] = valid ? key[i] : 0u;
+    v[st] = valid ? val[i] : 0u;
+    if (valid) atomicAdd(&off[w][(k[st] >> shift) & 255u], 1);  // counts only: order-independent
+  }
+  __syncthreads();
+  {  // (B) thread d: exclusive prefix over the 4 waves + global offset of (digit d, this block)
+    int run = hist_excl[(i64)tid * nblk + blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = off[j][tid]; off[j][tid] = run; run += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) {  // (C)
+    const i64 i = wbase + st * 64 + lane;
+    const bool valid = i < K;
+    const unsigned d = (k[st] >> shift) & 255u;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -221,13 +229,11 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const unsigned* key, const
       peers &= bit ? m : ~m;
     }
     const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));  // earlier lanes first: stable
-    const int pos = off[d];
-    __syncthreads();
-    if (valid && rank == 0) off[d] = pos + __builtin_popcountll(peers);
-    __syncthreads();
+    const int pos = off[w][d];
+    if (valid && rank == 0) off[w][d] = pos + __builtin_popcountll(peers);  // same wave: ordered after the read
     if (valid) {
-      key_out[pos + rank] = k;
-      val_out[pos + rank] = v;
+      key_out[pos + rank] = k[st];
+      val_out[pos + rank] = v[st];
     }
   }
 }
@@ -592,7 +598,7 @@ int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
     if (st != GCP_OK) return st;
-    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nblk), dim3(64), 0, stream, ks, vs, kd, vd, K, shift,
+    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, K, shift,
                        (const int*)hist_ex, (int)nblk);
     GCP_HIP(hipGetLastError());
     unsigned* t;

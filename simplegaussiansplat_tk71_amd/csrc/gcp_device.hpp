@@ -24,16 +24,6 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// Wave-wide sum, result broadcast to every lane (Kogge-Stone in DPP + readlane 63).
-__device__ __forceinline__ float wave_sum_f(float v) {
-  v += dpp_f<0x111, 0xf>(0.0f, v);
-  v += dpp_f<0x112, 0xf>(0.0f, v);
-  v += dpp_f<0x114, 0xf>(0.0f, v);
-  v += dpp_f<0x118, 0xf>(0.0f, v);
-  v += dpp_f<0x142, 0xa>(0.0f, v);
-  v += dpp_f<0x143, 0xc>(0.0f, v);
-  return readlane_f(v, 63);
-}
 // Wave-wide inclusive prefix sum of ints.
 __device__ __forceinline__ int wave_incl_scan_i(int v) {
   v += dpp_i<0x111, 0xf>(0, v);

@@ -34,6 +34,7 @@ __all__ = [
     "create_alpha_blend",
     "grad_cumsum",
     "create_alpha_brend_boxes",
+    "grad_cumsum_boxes",
     "custom_autograd_grouped_cumprod",
 ]
 
@@ -187,6 +188,22 @@ def grad_cumsum(rects, grad, cutting_number=None):
         mask = output != 0
         output = output[mask] - grad[mask]
         return [output, mask]
+
+
+def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
+    """`grad_cumsum` (gs_model.py:716-722) with the permutation taken from the tile binning instead of a sort
+    over all M pairs; same [values, mask] as `grad_cumsum(rects, grad)`."""
+    with torch.no_grad():
+        bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
+        pl = _raster.pixel_lists(bins, startpoint, endpoint)
+        index = pl.pair_index.long()
+        sorted_grad = grad[index]
+        output = torch.zeros_like(sorted_grad)
+        _ext.grouped_cumsum_reverse(sorted_grad, pl.pair_key, output)
+        unsorted = torch.empty_like(output)
+        unsorted[index] = output
+        mask = unsorted != 0
+        return [unsorted[mask] - grad[mask], mask]
 
 
 class custom_autograd_grouped_cumprod(torch.autograd.Function):

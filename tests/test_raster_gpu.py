@@ -216,5 +216,10 @@ def test_create_alpha_brend_from_boxes_equals_sort_route(device):
         a_vals, a_mask = ck.create_alpha_brend(rects, anti, flag)
         b_vals, b_mask = ck.create_alpha_brend_boxes(s, e, anti, 90, 70, flag)
         assert torch.equal(a_mask, b_mask) and torch.equal(a_vals, b_vals)
+    grad = torch.randn(rects.size(0), device=device, generator=torch.Generator(device=device).manual_seed(2))
+    grad[::23] = 0.0
+    a_vals, a_mask = ck.grad_cumsum(rects, grad)
+    b_vals, b_mask = ck.grad_cumsum_boxes(s, e, grad, 90, 70)
+    assert torch.equal(a_mask, b_mask) and torch.equal(a_vals, b_vals)
     pl = raster.pixel_lists(raster.bin_tiles(s, e, 90, 70), s, e)
     assert torch.equal(pl.pair_key, torch.sort(ck.unique(rects), stable=True).values)

@@ -80,7 +80,7 @@ def patch_stable_sort():
     torch.sort, torch.argsort = sort, argsort
 
 
-def make_scene(n_gauss, width, height, max_half, seed):
+def make_scene(n_gauss, width, height, max_half, seed, sig_min=0.6):
     g = torch.Generator().manual_seed(seed)
     mean = torch.stack(
         [torch.randint(0, width + 1, (n_gauss,), generator=g), torch.randint(0, height + 1, (n_gauss,), generator=g)], 1
@@ -90,8 +90,8 @@ def make_scene(n_gauss, width, height, max_half, seed):
     start = torch.minimum((mean - half).clamp(min=0), lim)
     end = torch.minimum((mean + half).clamp(min=0), lim)
     boxsize = torch.prod((end - start + 1).to(torch.int64), dim=1)
-    sx = 0.6 + 1.8 * torch.rand(n_gauss, generator=g)
-    sy = 0.6 + 1.8 * torch.rand(n_gauss, generator=g)
+    sx = sig_min + 1.8 * torch.rand(n_gauss, generator=g)
+    sy = sig_min + 1.8 * torch.rand(n_gauss, generator=g)
     rho = 0.8 * (torch.rand(n_gauss, generator=g) - 0.5)
     cov = torch.stack([sx * sx, rho * sx * sy, rho * sx * sy, sy * sy], 1).reshape(-1, 2, 2)
     vinv = torch.linalg.inv(cov).to(torch.float32).contiguous()
@@ -157,10 +157,16 @@ def main():
     scenes = {
         "fn_6g_16x12": (6, 16, 12, 3, 21, None),
         "fn_200g_64x48": (200, 64, 48, 6, 22, None),
+        "fn_1500g_128x96": (1500, 128, 96, 8, 23, None, 1.2),
+        # narrow Gaussians in wide boxes: g underflows to exactly 0 at box corners, a pixel's deepest pair then has
+        # an exactly-zero suffix sum, grad_cumsum's mask is not all True and — being returned in FLIPPED order
+        # (gs_model.py:720-722 vs its use at :642-645) — mis-selects rows: the reference's gradients are garbage here
+        "fn_300g_64x48_Q9_INFORMATIONAL": (300, 64, 48, 8, 30, None, 0.5),
         "fn_200g_64x48_2chunks_INFORMATIONAL": (200, 64, 48, 6, 22, 90),
     }
-    for name, (n_gauss, w, h, mh, seed, split) in scenes.items():
-        sc = make_scene(n_gauss, w, h, mh, seed)
+    for name, spec in scenes.items():
+        n_gauss, w, h, mh, seed, split = spec[:6]
+        sc = make_scene(n_gauss, w, h, mh, seed, *spec[6:])
         ends = [n_gauss] if split is None else [split, n_gauss]
         img, gv, go, gl = run_function(F, sc, w, h, ends)
         for k in ("boxsize", "start", "end", "mean", "vinv", "opacity", "l_d", "wimg"):

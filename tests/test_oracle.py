@@ -164,7 +164,7 @@ def test_empty_inputs():
     assert tp.grouped_cumprod(e, k).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["fn_6g_16x12", "fn_200g_64x48"])
+@pytest.mark.parametrize("name", ["fn_6g_16x12", "fn_200g_64x48", "fn_1500g_128x96"])
 def test_dense_renderer_vs_reference_function_golden(name):
     """a7: the dense autograd restatement reproduces the image and the opacity / precision-matrix
     gradients the reference's own Function produced (single chunk = the parity contract).  The
@@ -184,3 +184,20 @@ def test_dense_renderer_vs_reference_function_golden(name):
     torch.testing.assert_close(img32, g("image"), atol=1e-5, rtol=1e-5)
     # the reference's colour gradient differs from the true one by design
     assert not torch.allclose(gl.float(), g("grad_l_REFERENCE_BUGGY"), atol=1e-3, rtol=1e-2)
+
+
+def test_reference_backward_breaks_when_a_suffix_sum_is_exactly_zero():
+    """SURVEY §0 Q9 (found while building the goldens): `grad_cumsum` returns its mask in FLIPPED order
+    (gs_model.py:720-722) and `_backward_batch` applies it to un-flipped tensors (:642-645).  Harmless while the
+    mask is all True; with narrow Gaussians in wide boxes g underflows to exactly 0, a pixel's deepest pair then
+    has an exactly-zero suffix sum and the reference's gradients come out wrong, while its forward image is fine.
+    The golden keeps that case as information; the dense oracle (true gradients) is what the GPU path is held to."""
+    from oracle import dense_render as dr
+
+    z = np.load(os.path.join(GOLD, "function_golden.npz"))
+    name = "fn_300g_64x48_Q9_INFORMATIONAL"
+    g = lambda k: torch.from_numpy(z[f"{name}/{k}"])  # noqa: E731
+    w, h = (int(v) for v in z[name + "/width_height"])
+    img, gv, go, gl = dr.render_with_grads(g("start"), g("end"), g("mean"), g("vinv"), g("opacity"), g("l_d"), w, h, g("wimg"))
+    torch.testing.assert_close(img.float(), g("image"), atol=1e-5, rtol=1e-5)
+    assert (go.float() - g("grad_opacity")).abs().max() > 0.1  # the reference's own gradient is off by O(1)

@@ -70,7 +70,8 @@ __device__ __forceinline__ float exp_fast_accurate(float x) {
   float yl = __builtin_fmaf(x, kL2eHi, -yh);
   yl = __builtin_fmaf(x, kL2eLo, yl);
   const float e = __builtin_amdgcn_exp2f(yh);
-  return __builtin_fmaf(e, yl * kLn2, e);
+  const float r = __builtin_fmaf(e, yl * kLn2, e);
+  return (e < __builtin_inff()) ? r : e;  // overflow (indefinite Λ): inf like expf, not inf - inf
 }
 
 struct TileGrid { int tx, ty; };

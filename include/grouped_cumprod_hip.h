@@ -210,6 +210,16 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
  * prefix sums, pair_gauss[M] (Gaussian of every pair, pixel-major, depth order) and
  * pair_index[M] (the pair's position in the reference's Gaussian-major rect list) — i.e. the
  * `index` torch.sort(stable) returns at gs_model.py:547, bit for bit. */
+/* The reference's Gaussian-major rect list (Utilities.make_rect_points_parallel, uitility.py:336-366;
+ * _create_rects, gs_model.py:480-482) for callers that still want it: box sizes (clamped to the image), then —
+ * given their exclusive prefix sum box_off[N+1] — rects_xy int32[M,2] and optionally the owning Gaussian of
+ * every pair (gause_points_inv, gs_model.py:768-773). */
+int gcp_box_sizes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                  int32_t height, int32_t* box_size, void* stream);
+int gcp_expand_rects(const int32_t* start_xy, const int32_t* end_xy, const int32_t* box_off,
+                     int64_t n_gauss, int64_t n_pairs, int32_t width, int32_t height,
+                     int32_t* rects_xy, int32_t* pair_gauss /* may be NULL */, void* stream);
+
 int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
                           int32_t width, int32_t height, const int32_t* tile_start,
                           const int32_t* tile_list, int32_t* pixel_count, int32_t* box_size,

@@ -491,6 +491,27 @@ __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __r
   if (!FILL && in_img) pixel_count[(i64)py * (a.W + 1) + px] = n;
 }
 
+// Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
+// _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
+// One thread per pair; the owning Gaussian is found by bisection in the box offsets.
+__global__ void k_expand_rects(const int* start, const int* end, const int* box_off, i64 n_gauss, i64 m, int W, int H,
+                               int* rects /*[m][2]*/, int* pair_gauss /*[m] or null*/) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  i64 lo = 0, hi = n_gauss;  // last g with box_off[g] <= i
+  while (hi - lo > 1) {
+    const i64 mid = (lo + hi) >> 1;
+    if (box_off[mid] <= i) lo = mid; else hi = mid;
+  }
+  Box b;
+  load_box(start, end, lo, W, H, b);
+  const int local = (int)(i - box_off[lo]);
+  const int w = b.x1 - b.x0 + 1;
+  rects[2 * i] = b.x0 + local % w;
+  rects[2 * i + 1] = b.y0 + local / w;
+  if (pair_gauss) pair_gauss[i] = (int)lo;
+}
+
 __global__ void k_box_sizes(const int* start, const int* end, i64 n, int W, int H, int* size) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -685,6 +706,31 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
                        (i64)n_gauss, width, height, box_size);
     GCP_HIP(hipGetLastError());
   }
+  return GCP_OK;
+}
+
+int gcp_box_sizes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                  int32_t* box_size, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_gauss < 0 || width < 0 || height < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !box_size) return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_box_sizes, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                     (i64)n_gauss, width, height, box_size);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_expand_rects(const int32_t* start_xy, const int32_t* end_xy, const int32_t* box_off, int64_t n_gauss,
+                     int64_t n_pairs, int32_t width, int32_t height, int32_t* rects_xy, int32_t* pair_gauss,
+                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_gauss < 0 || n_pairs < 0 || width < 0 || height < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_pairs == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !box_off || !rects_xy || n_gauss == 0) return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_expand_rects, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                     box_off, (i64)n_gauss, (i64)n_pairs, width, height, rects_xy, pair_gauss);
+  GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 

@@ -196,3 +196,29 @@ def pixel_lists(bins, startpoint, endpoint):
             "gcp_pixel_lists_fill",
         )
     return PixelLists(pixel_off, pair_gauss[:m], pair_index[:m], pair_key[:m], box_off)
+
+
+def expand_rects(startpoint, endpoint, width, height, with_gaussian=False):
+    """The reference's rect list: every pixel of every box, Gaussian-major, row-major inside a box
+    (Utilities.make_rect_points_parallel, uitility.py:336-366 -> _create_rects, gs_model.py:480-482).
+    Returns rects int32[M,2] (x,y) [, pair_gauss int32[M] = gause_points_inv, gs_model.py:768-773]."""
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    n = start.size(0)
+    dev = start.device
+    lib = _lib.load()
+    width, height = int(width), int(height)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        bsize = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.gcp_box_sizes(start.data_ptr(), end.data_ptr(), n, width, height, bsize.data_ptr(), st), "gcp_box_sizes")
+        box_off = exclusive_scan_i32(bsize[:n])
+        m = int(box_off[-1].item())  # the reference synchronises here too (uitility.py:348)
+        rects = torch.empty(m, 2, dtype=torch.int32, device=dev)
+        owner = torch.empty(m, dtype=torch.int32, device=dev) if with_gaussian else None
+        _lib.check(
+            lib.gcp_expand_rects(start.data_ptr(), end.data_ptr(), box_off.data_ptr(), n, m, width, height, rects.data_ptr(),
+                                 owner.data_ptr() if with_gaussian else None, st),
+            "gcp_expand_rects",
+        )
+    return (rects, owner) if with_gaussian else rects

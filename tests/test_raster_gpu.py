@@ -263,3 +263,22 @@ def test_blend_extreme_exponents(device):
     torch.testing.assert_close(img[0, 0], torch.full((3,), 0.9, device=device))            # g = 1 at the centre
     assert float(img[15, 15].abs().max()) == 0.0                                           # exp(-9000) -> 0
     torch.testing.assert_close(img[8, 8], torch.full((3,), 0.5, device=device))            # untouched by Gaussian 0's tail
+
+
+def test_expand_rects_matches_reference_order(device):
+    """Utilities.make_rect_points_parallel (uitility.py:336-366): Gaussian-major, row-major inside each box."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(250, 70, 45, 9, 61)
+    s, e = sc["start"], sc["end"]
+    rects, owner = raster.expand_rects(s.to(device), e.to(device), 70, 45, with_gaussian=True)
+    want, wg = [], []
+    for g in range(s.size(0)):
+        ys = torch.arange(int(s[g, 1]), int(e[g, 1]) + 1)
+        xs = torch.arange(int(s[g, 0]), int(e[g, 0]) + 1)
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        want.append(torch.stack([xx.flatten(), yy.flatten()], 1))
+        wg.append(torch.full((xx.numel(),), g))
+    assert torch.equal(rects.cpu().long(), torch.cat(want))
+    assert torch.equal(owner.cpu().long(), torch.cat(wg))
+    assert rects.size(0) == int(sc["boxsize"].sum())

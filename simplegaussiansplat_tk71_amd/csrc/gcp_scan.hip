@@ -145,27 +145,30 @@ __device__ __forceinline__ float wave_reduce(float v) {
 // allocations always are); otherwise dword accesses.
 // ----------------------------------------------------------------------------
 // Cache policy of the streaming accesses (A/B on cfg3, one process, interleaved): non-temporal STORES
-// +1.8 % (forward) / +3.9 % (backward); non-temporal LOADS -7 % (the look-back re-reads the neighbouring
-// tile's tail and wants it cached).
+// +1.8 % (forward) / +3.9 % (backward).  Non-temporal LOADS of everything: -7 % with the look-back loads
+// included, +1.7 % forward / -3.5 % backward with only the tile loads (and -15 % on cache-resident cfg2):
+// the look-back re-reads the END of the neighbouring tile and wants it cached.  Mode 2 — non-temporal for
+// all waves but the last one in scan order, plus `param` in the backward, which no look-back touches —
+// is neutral on the forward and cfg2 and +1.3 % on the backward.
 #ifndef GCP_NT_LOAD
-#define GCP_NT_LOAD 0
+#define GCP_NT_LOAD 2
 #endif
 #ifndef GCP_NT_STORE
 #define GCP_NT_STORE 1
 #endif
-template <bool ALIGNED>
+template <bool ALIGNED, bool NT = false>
 __device__ __forceinline__ float4_t ld4(const float* p) {
   if (ALIGNED) {
-    if (GCP_NT_LOAD) return __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(p));
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(p));
     return *reinterpret_cast<const float4_t*>(p);
   }
   float4_t v; v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
   return v;
 }
-template <bool ALIGNED>
+template <bool ALIGNED, bool NT = false>
 __device__ __forceinline__ int4_t ld4(const int* p) {
   if (ALIGNED) {
-    if (GCP_NT_LOAD) return __builtin_nontemporal_load(reinterpret_cast<const int4_t*>(p));
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const int4_t*>(p));
     return *reinterpret_cast<const int4_t*>(p);
   }
   int4_t v; v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
@@ -237,6 +240,10 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   const i64 base = pt * (i64)kTile;
 
   // ---- issue all loads of this lane ------------------------------------
+  // Streaming (non-temporal) loads are faster for bytes nobody reads again, but the END of a tile (scan
+  // order) is what the next tile's look-back re-reads and must stay cached: GCP_NT_LOAD 0 = never,
+  // 1 = all tile loads, 2 = all waves but the last one in scan order.
+  const bool nt_main = (GCP_NT_LOAD == 1) || (GCP_NT_LOAD == 2 && w < kWaves - 1);
   float4_t v[kRows];
   int4_t kk[kRows];
   float4_t xp[BWD ? kRows : 1];
@@ -246,15 +253,22 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     const int q = w * WT + r * 256 + lane * 4;
     p0[r] = REV ? (base + kTile - 4 - q) : (base + q);
     if (FULL) {
-      kk[r] = ld4<ALIGNED>(a.key + p0[r]);
-      if constexpr (BWD) {
-        const float4_t g = ld4<ALIGNED>(a.in2 + p0[r]);
-        const float4_t c = ld4<ALIGNED>(a.in1 + p0[r]);
-        xp[r] = ld4<ALIGNED>(a.in0 + p0[r]);
-        v[r] = g * c;
+      if (nt_main) {  // wave-uniform
+        kk[r] = ld4<ALIGNED, true>(a.key + p0[r]);
+        if constexpr (BWD) {
+          v[r] = ld4<ALIGNED, true>(a.in2 + p0[r]) * ld4<ALIGNED, true>(a.in1 + p0[r]);
+        } else {
+          v[r] = ld4<ALIGNED, true>(a.in0 + p0[r]);
+        }
       } else {
-        v[r] = ld4<ALIGNED>(a.in0 + p0[r]);
+        kk[r] = ld4<ALIGNED>(a.key + p0[r]);
+        if constexpr (BWD) {
+          v[r] = ld4<ALIGNED>(a.in2 + p0[r]) * ld4<ALIGNED>(a.in1 + p0[r]);
+        } else {
+          v[r] = ld4<ALIGNED>(a.in0 + p0[r]);
+        }
       }
+      if constexpr (BWD) xp[r] = ld4<ALIGNED, (GCP_NT_LOAD != 0)>(a.in0 + p0[r]);  // param is never re-read by a look-back
     } else {
       kk[r] = ld4_guard(a.key, p0[r], n, 0);
       if constexpr (BWD) {

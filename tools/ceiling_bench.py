@@ -32,9 +32,11 @@ def main():
     ops = {
         "ideal 12B (2R+1W)": (lambda: lib.ceiling12(p.x.data_ptr(), p.key.data_ptr(), g.data_ptr(), m, 0, st), 12),
         "ideal 12B nt-store": (lambda: lib.ceiling12(p.x.data_ptr(), p.key.data_ptr(), g.data_ptr(), m, 1, st), 12),
+        "ideal 12B nt-ld+st": (lambda: lib.ceiling12(p.x.data_ptr(), p.key.data_ptr(), g.data_ptr(), m, 2, st), 12),
         "cumprod_fwd": (lambda: gc.grouped_cumprod_forward(p.x, p.key, y), 12),
         "ideal 20B (4R+1W)": (lambda: lib.ceiling20(p.x.data_ptr(), y.data_ptr(), p.grad_out.data_ptr(), p.inv.data_ptr(), g.data_ptr(), m, 0, st), 20),
         "ideal 20B nt-store": (lambda: lib.ceiling20(p.x.data_ptr(), y.data_ptr(), p.grad_out.data_ptr(), p.inv.data_ptr(), g.data_ptr(), m, 1, st), 20),
+        "ideal 20B nt-ld+st": (lambda: lib.ceiling20(p.x.data_ptr(), y.data_ptr(), p.grad_out.data_ptr(), p.inv.data_ptr(), g.data_ptr(), m, 2, st), 20),
         "cumprod_bwd": (lambda: gc.grouped_cumprod_backward(p.x, y, p.grad_out, p.inv, g, p.inv_len), 20),
     }
     res = {k: [] for k in ops}

@@ -149,14 +149,19 @@ __device__ __forceinline__ bool load_box(const int* start, const int* end, i64 g
   return b.x1 >= b.x0 && b.y1 >= b.y0;
 }
 
-__global__ void k_tile_count(const int* start, const int* end, i64 n, int W, int H, int* cnt) {
+__global__ __launch_bounds__(256) void k_tile_count(const int* start, const int* end, i64 n, int W, int H, int* cnt,
+                                                     unsigned long long* total64) {
+  __shared__ int s_w[4];
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
   Box b;
   int c = 0;
-  if (load_box(start, end, g, W, H, b))
+  if (g < n && load_box(start, end, g, W, H, b))
     c = ((b.x1 >> 4) - (b.x0 >> 4) + 1) * ((b.y1 >> 4) - (b.y0 >> 4) + 1);
-  cnt[g] = c;
+  if (g < n) cnt[g] = c;
+  // 64-bit total beside the int32 prefix sums: lets the host refuse a K that does not fit int32
+  int block_total;
+  block_excl_scan_256(c, s_w, block_total);
+  if (threadIdx.x == 0 && block_total) atomicAdd(total64, (unsigned long long)block_total);
 }
 
 __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
@@ -554,19 +559,22 @@ int gcp_bin_tiles_count(const int32_t* start_xy, const int32_t* end_xy, int64_t 
     return GCP_OK;
   }
   if (!start_xy || !end_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
-  const size_t need = align256((size_t)n_gauss * sizeof(int)) + gcp_scan_i32_workspace_bytes(n_gauss);
+  const size_t need = 256 + align256((size_t)n_gauss * sizeof(int)) + gcp_scan_i32_workspace_bytes(n_gauss);
   if (ws_bytes < need) return GCP_ERR_WORKSPACE;
-  int* cnt = (int*)ws;
-  int* sws = (int*)((char*)ws + align256((size_t)n_gauss * sizeof(int)));
+  unsigned long long* total64 = (unsigned long long*)ws;
+  int* cnt = (int*)((char*)ws + 256);
+  int* sws = (int*)((char*)ws + 256 + align256((size_t)n_gauss * sizeof(int)));
+  GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
-                     (i64)n_gauss, width, height, cnt);
+                     (i64)n_gauss, width, height, cnt, total64);
   GCP_HIP(hipGetLastError());
   const int st = launch_excl_scan(cnt, tile_off, n_gauss, sws, stream);
   if (st != GCP_OK) return st;
-  int total = 0;
-  GCP_HIP(hipMemcpyAsync(&total, tile_off + n_gauss, sizeof(int), hipMemcpyDeviceToHost, stream));
+  unsigned long long total = 0;
+  GCP_HIP(hipMemcpyAsync(&total, total64, sizeof(total), hipMemcpyDeviceToHost, stream));
   GCP_HIP(hipStreamSynchronize(stream));
-  *n_tile_pairs_host = total;
+  if (total > 0x7fffffffull) return GCP_ERR_INVALID_ARGUMENT;  // (tile, Gaussian) entries are indexed with int32
+  *n_tile_pairs_host = (int64_t)total;
   return GCP_OK;
 }
 
@@ -577,7 +585,7 @@ size_t gcp_bin_workspace_bytes(int64_t n_gauss, int64_t n_tile_pairs) {
   b += 3 * align256((size_t)k * sizeof(unsigned));                 // key A, key B, val B
   b += 2 * align256((size_t)(256 * nblk + 1) * sizeof(int));       // hist, hist_excl
   b += gcp_scan_i32_workspace_bytes(256 * nblk);
-  const size_t count_need = align256((size_t)(n_gauss > 0 ? n_gauss : 1) * sizeof(int)) +
+  const size_t count_need = 256 + align256((size_t)(n_gauss > 0 ? n_gauss : 1) * sizeof(int)) +
                             gcp_scan_i32_workspace_bytes(n_gauss > 0 ? n_gauss : 1);
   return b > count_need ? b : count_need;
 }

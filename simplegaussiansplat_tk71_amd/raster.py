@@ -181,6 +181,8 @@ def pixel_lists(bins, startpoint, endpoint):
                                       bsize.data_ptr(), st),
             "gcp_pixel_lists_count",
         )
+        total = int(bsize[: bins.n_gauss].sum(dtype=torch.int64).item())
+        _require(total < 2**31, f"pixel lists: {total} pairs do not fit the int32 offsets of the pair arrays")
         pixel_off = exclusive_scan_i32(count)
         box_off = exclusive_scan_i32(bsize[: bins.n_gauss])
         m = int(pixel_off[-1].item())

@@ -282,3 +282,14 @@ def test_expand_rects_matches_reference_order(device):
     assert torch.equal(rects.cpu().long(), torch.cat(want))
     assert torch.equal(owner.cpu().long(), torch.cat(wg))
     assert rects.size(0) == int(sc["boxsize"].sum())
+
+
+def test_bin_tiles_refuses_more_than_int32_entries(device):
+    """80 000 Gaussians that each cover a 3840x2160 frame would need 2.6e9 (tile, Gaussian) entries."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    n = 80_000
+    start = torch.zeros(n, 2, dtype=torch.int32, device=device)
+    end = torch.tensor([[3839, 2159]], dtype=torch.int32, device=device).repeat(n, 1)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        raster.bin_tiles(start, end, 3839, 2159)

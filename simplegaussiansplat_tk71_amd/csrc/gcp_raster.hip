@@ -59,21 +59,6 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-// exp(x) as exp2 of a compensated product: y = x*log2(e) is formed as hi + lo (fma residual + the
-// low word of log2(e)), v_exp_f32 takes the high part and the low part enters as a first-order
-// correction.  ~1 ulp like libm's expf, 6 VALU instead of 13 (no range reduction / ldexp / special
-// casing: overflow gives inf, underflow 0 on its own).  Tiny results (< 2^-126) flush to 0, which
-// only ever multiplies an opacity.
-__device__ __forceinline__ float exp_fast_accurate(float x) {
-  const float kL2eHi = 1.44269502e+00f, kL2eLo = 1.92596299e-08f, kLn2 = 6.93147182e-01f;
-  const float yh = x * kL2eHi;
-  float yl = __builtin_fmaf(x, kL2eHi, -yh);
-  yl = __builtin_fmaf(x, kL2eLo, yl);
-  const float e = __builtin_amdgcn_exp2f(yh);
-  const float r = __builtin_fmaf(e, yl * kLn2, e);
-  return (e < __builtin_inff()) ? r : e;  // overflow (indefinite Λ): inf like expf, not inf - inf
-}
-
 struct TileGrid { int tx, ty; };
 inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTile - 1) / kTile, (H + 1 + kTile - 1) / kTile}; }
 
@@ -272,7 +257,7 @@ template <int STAGE>
 struct Staged {
   int4 box[STAGE];     // x0, y0, x1-x0, y1-y0 (clamped to the image)
   float4 geo[STAGE];   // mx, my, opacity, 1/opacity (0 if opacity == 0)
-  float4 vin[STAGE];   // a b c d  (Λ = [[a,b],[c,d]])
+  float4 vin[STAGE];   // a b c d of Λ' = -0.5*log2(e) * Λ  (Λ = [[a,b],[c,d]])
   float4 col[STAGE];   // l0 l1 l2 -
 };
 
@@ -285,12 +270,27 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     s.box[j] = make_int4(b.x0, b.y0, b.x1 - b.x0, b.y1 - b.y0);  // origin + extent: one unsigned compare per axis
     const float op = a.opacity[g];
     s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], op, op != 0.0f ? 1.0f / op : 0.0f);
-    s.vin[j] = make_float4(a.vinv[4 * g], a.vinv[4 * g + 1], a.vinv[4 * g + 2], a.vinv[4 * g + 3]);
+    // Λ pre-scaled by -0.5*log2(e): g = exp(-0.5 d Λ d^T) becomes ONE v_exp_f32 of d Λ' d^T.  The extra rounding of
+    // Λ' moves g by < 1e-7 absolute (relative 6e-8*|log2 g|, and g decays as fast as that factor grows).
+    constexpr float kS = -0.5f * 1.44269504088896341f;
+    s.vin[j] = make_float4(kS * a.vinv[4 * g], kS * a.vinv[4 * g + 1], kS * a.vinv[4 * g + 2], kS * a.vinv[4 * g + 3]);
     s.col[j] = make_float4(a.l_d[3 * g], a.l_d[3 * g + 1], a.l_d[3 * g + 2], 0.0f);
   }
 }
 
+#ifndef GCP_BLEND_FMA
+#define GCP_BLEND_FMA 1
+#endif
+#if GCP_BLEND_FMA
+// The blend kernels are VALU-issue bound: let a*b+c contract into v_fma_f32 here (the library is otherwise built
+// with -ffp-contract=off).  One rounding instead of two per contraction; results stay within the 1e-5 bar.
+#define GCP_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define GCP_FP_CONTRACT
+#endif
+
 __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __restrict__ image) {
+  GCP_FP_CONTRACT
   __shared__ Staged<kStage> s;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int tile = blockIdx.x;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
         // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
         const float t0 = dx * vi.x + dy * vi.z;
         const float t1 = dx * vi.y + dy * vi.w;
-        const float g = exp_fast_accurate(-0.5f * (t0 * dx + t1 * dy));
+        const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
         const float anti = 1.0f - ge.z * g;             // gs_model.py:535
         const float incl = T * anti;                    // inclusive grouped cumprod
         if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
                                                    const float* __restrict__ image,
                                                    const float* __restrict__ grad_image,
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
+  GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
   __shared__ float s_part[kStageBwd][16][kRowVals];  // [entry][pixel row of the tile][value]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         const float dx = fx - ge.x, dy = fy - ge.y;
         const float t0 = dx * vi.x + dy * vi.z;
         const float t1 = dx * vi.y + dy * vi.w;
-        const float g = exp_fast_accurate(-0.5f * (t0 * dx + t1 * dy));
+        const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
         const float op = ge.z;
         const float anti = 1.0f - op * g;
         const float incl = T * anti;

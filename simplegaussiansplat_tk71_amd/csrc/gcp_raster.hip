@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
       const int4 bx = s.box[k];
       const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) continue;
-      if (in) {
+      if (in) {  // (the branch-free form that pays off in the backward is 7 % slower here)
         const float4 ge = s.geo[k];
         const float4 vi = s.vin[k];
         const float4 co = s.col[k];
@@ -367,34 +367,35 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         if (lane < 4 * kRowVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
         continue;
       }
-      float r_o = 0.0f, r_l0 = 0.0f, r_l1 = 0.0f, r_l2 = 0.0f, r_c = 0.0f, r_cx = 0.0f, r_xx = 0.0f;
-      if (in) {
-        const float4 ge = s.geo[k];
-        const float4 vi = s.vin[k];
-        const float4 co = s.col[k];
-        const float dx = fx - ge.x, dy = fy - ge.y;
-        const float t0 = dx * vi.x + dy * vi.z;
-        const float t1 = dx * vi.y + dy * vi.w;
-        const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
-        const float op = ge.z;
-        const float anti = 1.0f - op * g;
-        const float incl = T * anti;
-        if (incl != 0.0f) {
-          const float wgt = T * op * g;
-          const float gp = g0 * (wgt * co.x) + g1 * (wgt * co.y) + g2 * (wgt * co.z);  // gs_model.py:632
-          acc += gp;
-          const float S = gC - acc;                 // exclusive suffix sum of gp (gs_model.py:716-722)
-          const float sa = S * __builtin_amdgcn_rcpf(anti);          // S / anti (v_rcp_f32, 1 ulp)
-          r_o = -(g * sa) + gp * ge.w;                              // gs_model.py:733-740 (gp / o, o != 0)
-          r_l0 = g0 * wgt; r_l1 = g1 * wgt; r_l2 = g2 * wgt;        // true dL/dl (reference: gp / l, Q2)
-          const float common = gp - (op * g) * sa;                  // gs_model.py:747-748, :757-758
-          r_c = common; r_cx = common * dx; r_xx = r_cx * dx;
-        }
-        T = incl;
-      }
+      // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
+      const float4 ge = s.geo[k];
+      const float4 vi = s.vin[k];
+      const float4 co = s.col[k];
+      const float dx = fx - ge.x, dy = fy - ge.y;
+      const float t0 = dx * vi.x + dy * vi.z;
+      const float t1 = dx * vi.y + dy * vi.w;
+      const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
+      const float op = ge.z;
+      const float anti = 1.0f - op * g;
+      const float incl = T * anti;
+      const bool keep = in & (incl != 0.0f);
+      const float wgt = keep ? T * op * g : 0.0f;
+      const float gp = g0 * (wgt * co.x) + g1 * (wgt * co.y) + g2 * (wgt * co.z);  // gs_model.py:632
+      acc += gp;
+      const float S = gC - acc;                          // exclusive suffix sum of gp (gs_model.py:716-722)
+      const float sa = S * __builtin_amdgcn_rcpf(anti);   // S / anti (v_rcp_f32, 1 ulp)
+      float r_o = keep ? gp * ge.w - g * sa : 0.0f;       // gs_model.py:733-740 (gp / o for o != 0)
+      float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;  // true dL/dl (reference: gp / l, Q2)
+      float r_c = keep ? gp - (op * g) * sa : 0.0f;       // gs_model.py:747-748, :757-758
+      float r_cx = r_c * dx;
+      float r_xx = r_cx * dx;
+      T = in ? incl : T;
       r_o = row_sum16(r_o);
       r_l0 = row_sum16(r_l0); r_l1 = row_sum16(r_l1); r_l2 = row_sum16(r_l2);
       r_c = row_sum16(r_c); r_cx = row_sum16(r_cx); r_xx = row_sum16(r_xx);
+      // keep the last DPP add fused and outside the lane-15 branch (hipcc otherwise sinks it there as
+      // v_mov 0 + v_mov_b32_dpp + v_add)
+      asm volatile("" : "+v"(r_o), "+v"(r_l0), "+v"(r_l1), "+v"(r_l2), "+v"(r_c), "+v"(r_cx), "+v"(r_xx));
       if ((lane & 15) == 15) {
         float* d = s_part[k][w * 4 + (lane >> 4)];
         d[0] = r_o; d[1] = r_l0; d[2] = r_l1; d[3] = r_l2; d[4] = r_c; d[5] = r_cx; d[6] = r_xx;

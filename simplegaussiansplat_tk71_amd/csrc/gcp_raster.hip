@@ -136,17 +136,23 @@ __device__ __forceinline__ bool load_box(const int* start, const int* end, i64 g
 
 __global__ __launch_bounds__(256) void k_tile_count(const int* start, const int* end, i64 n, int W, int H, int* cnt,
                                                      unsigned long long* total64) {
-  __shared__ int s_w[4];
-  const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  Box b;
-  int c = 0;
-  if (g < n && load_box(start, end, g, W, H, b))
-    c = ((b.x1 >> 4) - (b.x0 >> 4) + 1) * ((b.y1 >> 4) - (b.y0 >> 4) + 1);
-  if (g < n) cnt[g] = c;
-  // 64-bit total beside the int32 prefix sums: lets the host refuse a K that does not fit int32
-  int block_total;
-  block_excl_scan_256(c, s_w, block_total);
-  if (threadIdx.x == 0 && block_total) atomicAdd(total64, (unsigned long long)block_total);
+  __shared__ unsigned long long s_total;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  // grid-stride: few blocks, so the 64-bit total (which lets the host refuse a K that does not fit the int32
+  // prefix sums) costs a few hundred atomics, not one per 256 Gaussians
+  unsigned long long wide = 0;
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (i64)gridDim.x * blockDim.x) {
+    Box b;
+    int c = 0;
+    if (load_box(start, end, g, W, H, b))
+      c = ((b.x1 >> 4) - (b.x0 >> 4) + 1) * ((b.y1 >> 4) - (b.y0 >> 4) + 1);
+    cnt[g] = c;
+    wide += (unsigned long long)c;
+  }
+  if (wide) atomicAdd(&s_total, wide);  // integer adds: order-independent, deterministic
+  __syncthreads();
+  if (threadIdx.x == 0 && s_total) atomicAdd(total64, s_total);
 }
 
 __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
@@ -567,7 +573,8 @@ int gcp_bin_tiles_count(const int32_t* start_xy, const int32_t* end_xy, int64_t 
   int* cnt = (int*)((char*)ws + 256);
   int* sws = (int*)((char*)ws + 256 + align256((size_t)n_gauss * sizeof(int)));
   GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
-  hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+  const i64 count_blocks = (n_gauss + 255) / 256 < 512 ? (n_gauss + 255) / 256 : 512;
+  hipLaunchKernelGGL(k_tile_count, dim3((unsigned)count_blocks), dim3(256), 0, stream, start_xy, end_xy,
                      (i64)n_gauss, width, height, cnt, total64);
   GCP_HIP(hipGetLastError());
   const int st = launch_excl_scan(cnt, tile_off, n_gauss, sws, stream);

@@ -31,13 +31,15 @@ def render(start, end, mean, vinv, opacity, l_d, width, height, dtype=torch.floa
     vinv = vinv.to(dtype)
     opacity = opacity.to(dtype)
     l_d = l_d.to(dtype)
+    # a float `mean` that requires grad is differentiated through (the reference passes ints); plain numbers otherwise
+    mean_t = mean.to(dtype) if mean.requires_grad else mean.to(dtype).tolist()
     for i in range(n):
         x0, y0 = int(start[i, 0]), int(start[i, 1])
         x1, y1 = int(end[i, 0]), int(end[i, 1])
         if x1 < x0 or y1 < y0:
             continue
-        dx = xs[:, x0 : x1 + 1] - float(mean[i, 0])
-        dy = ys[y0 : y1 + 1, :] - float(mean[i, 1])
+        dx = xs[:, x0 : x1 + 1] - mean_t[i][0]
+        dy = ys[y0 : y1 + 1, :] - mean_t[i][1]
         a, b, c, d = vinv[i, 0, 0], vinv[i, 0, 1], vinv[i, 1, 0], vinv[i, 1, 1]
         q = (dx * a + dy * c) * dx + (dx * b + dy * d) * dy  # (d Λ) d^T, association of gs_model.py:495
         g = torch.exp(-0.5 * q)
@@ -52,11 +54,14 @@ def render(start, end, mean, vinv, opacity, l_d, width, height, dtype=torch.floa
     return img
 
 
-def render_with_grads(start, end, mean, vinv, opacity, l_d, width, height, grad_image, dtype=torch.float64):
-    """Image and the true gradients w.r.t. (vinv, opacity, l_d) for the loss <image, grad_image>."""
+def render_with_grads(start, end, mean, vinv, opacity, l_d, width, height, grad_image, dtype=torch.float64, with_mean=False):
+    """Image and the true gradients w.r.t. (vinv, opacity, l_d[, mean]) for the loss <image, grad_image>."""
     v = vinv.detach().to(dtype).clone().requires_grad_(True)
     o = opacity.detach().to(dtype).clone().requires_grad_(True)
     l = l_d.detach().to(dtype).clone().requires_grad_(True)
-    img = render(start, end, mean, v, o, l, width, height, dtype)
+    m = mean.detach().to(dtype).clone().requires_grad_(with_mean)
+    img = render(start, end, m if with_mean else mean, v, o, l, width, height, dtype)
     (img * grad_image.to(dtype)).sum().backward()
+    if with_mean:
+        return img.detach(), v.grad, o.grad, l.grad, m.grad
     return img.detach(), v.grad, o.grad, l.grad

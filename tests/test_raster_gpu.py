@@ -293,3 +293,41 @@ def test_bin_tiles_refuses_more_than_int32_entries(device):
     end = torch.tensor([[3839, 2159]], dtype=torch.int32, device=device).repeat(n, 1)
     with pytest.raises(RuntimeError, match="invalid argument"):
         raster.bin_tiles(start, end, 3839, 2159)
+
+
+def test_gradient_wrt_float_means(device):
+    """The reference computes dL/dmean (gs_model.py:743-750) but feeds integer means, so autograd drops it
+    (SURVEY §0 Q5).  With float means the Function returns it; for symmetric precision matrices it is the true
+    gradient: compare with the dense autograd oracle."""
+    import cuda_kernel as ck
+    from oracle import dense_render as dr
+
+    sc = make_scene(300, 70, 50, 6, 71)
+    mean_f = sc["mean"].float() + 0.25  # off-grid centres
+    vinv = sc["vinv"].to(device)
+    op = sc["opacity"].to(device)
+    l_d = sc["l_d"].to(device)
+    m = mean_f.to(device).requires_grad_(True)
+    n = sc["start"].size(0)
+    img = ck.custom_autograd_grouped_cumprod.apply(sc["boxsize"].to(device), torch.tensor([n], device=device), sc["start"].to(device),
+                                                   sc["end"].to(device), m, vinv, op, l_d, 70, 50)
+    (img * sc["wimg"].to(device)).sum().backward()
+    _, _, _, _, gm64 = dr.render_with_grads(sc["start"], sc["end"], mean_f, sc["vinv"], sc["opacity"], sc["l_d"], 70, 50, sc["wimg"], with_mean=True)
+    _close(m.grad.cpu(), gm64, gm64.abs().mean().item(), "grad_mean")
+
+
+def test_all_boxes_empty(device):
+    """Gaussians whose boxes miss the image entirely: no tile entries, zero image, zero gradients."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    n = 50
+    start = torch.full((n, 2), 40, dtype=torch.int32, device=device)
+    end = torch.full((n, 2), 39, dtype=torch.int32, device=device)  # end < start
+    bins = raster.bin_tiles(start, end, 31, 17)
+    assert bins.n_tile_pairs == 0
+    args = (start, end, start.float(), torch.eye(2, device=device).repeat(n, 1, 1), torch.full((n, 1), 0.5, device=device),
+            torch.ones(n, 3, device=device))
+    img = raster.blend_forward(bins, *args)
+    assert float(img.abs().sum()) == 0.0
+    grads = raster.blend_backward(bins, *args, img, torch.ones_like(img))
+    assert all(float(g.abs().sum()) == 0.0 for g in grads)

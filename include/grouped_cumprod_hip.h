@@ -210,6 +210,15 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
  * prefix sums, pair_gauss[M] (Gaussian of every pair, pixel-major, depth order) and
  * pair_index[M] (the pair's position in the reference's Gaussian-major rect list) — i.e. the
  * `index` torch.sort(stable) returns at gs_model.py:547, bit for bit. */
+/* Stable sort of n uint32 keys that also returns the permutation: keys_out[i] = keys_in[index_out[i]], equal
+ * keys keep their input order — what the reference asks of torch.sort for its pixel keys (gs_model.py:546-547;
+ * depth order inside a pixel rides on that stability).  LSD radix sort over the low `key_bits` bits (8 per
+ * pass; the keys must be < 2^key_bits), deterministic (no atomic decides a slot).  n < 2^31.
+ * ws: gcp_sort_workspace_bytes(n) bytes. */
+size_t gcp_sort_workspace_bytes(int64_t n);
+int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out,
+                       int32_t* index_out, void* ws, size_t ws_bytes, void* stream);
+
 /* The reference's Gaussian-major rect list (Utilities.make_rect_points_parallel, uitility.py:336-366;
  * _create_rects, gs_model.py:480-482) for callers that still want it: box sizes (clamped to the image), then —
  * given their exclusive prefix sum box_off[N+1] — rects_xy int32[M,2] and optionally the owning Gaussian of

@@ -235,6 +235,92 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const unsigned* key, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// General stable sort of (key, index) pairs for M-sized inputs (the pixel-key sort of the reference's
+// _create_alpha_brend, gs_model.py:546-547): same LSD passes, but 4096-key blocks whose output is first
+// arranged in LDS in digit order and then copied out, so every digit's run leaves the block as one
+// contiguous (coalesced) global write instead of 4-byte scatters.
+// ------------------------------------------------------------------------------------------
+constexpr int kBigChunk = 4096;
+
+__global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const i64 base = (i64)blockIdx.x * kBigChunk;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < kBigChunk; i += 256)
+    if (base + i < n) atomicAdd(&h[(key[base + i] >> shift) & 255u], 1);
+  __syncthreads();
+  hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+template <bool FIRST>  // FIRST: the payload is the element's own index
+__global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
+                                                       unsigned* val_out, i64 n, int shift, const int* hist_excl,
+                                                       int nblk) {
+  __shared__ unsigned s_key[kBigChunk];
+  __shared__ unsigned s_val[kBigChunk];
+  __shared__ int off[4][256];   // (A) per-wave digit counts -> (B) first LDS slot of (wave, digit)
+  __shared__ int gdelta[256];   // global slot = LDS slot + gdelta[digit]
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int d = lane; d < 256; d += 64) off[w][d] = 0;
+  __syncthreads();
+  const i64 bbase = (i64)blockIdx.x * kBigChunk;
+  const i64 wbase = bbase + (i64)w * (kBigChunk / 4);
+  constexpr int kSteps = kBigChunk / 4 / 64;  // 16
+  unsigned k[kSteps], v[kSteps];
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) {  // (A)
+    const i64 i = wbase + st * 64 + lane;
+    const bool valid = i < n;
+    k[st] = valid ? key[i] : 0u;
+    v[st] = FIRST ? (unsigned)i : (valid ? val[i] : 0u);
+    if (valid) atomicAdd(&off[w][(k[st] >> shift) & 255u], 1);  // counts only: order-independent
+  }
+  __syncthreads();
+  {  // (B) thread d: digit total -> block-wide exclusive prefix over digits -> per-wave LDS bases
+    const int c0 = off[0][tid], c1 = off[1][tid], c2 = off[2][tid], c3 = off[3][tid];
+    int total;
+    const int lstart = block_excl_scan_256(c0 + c1 + c2 + c3, s_w, total);
+    off[0][tid] = lstart;
+    off[1][tid] = lstart + c0;
+    off[2][tid] = lstart + c0 + c1;
+    off[3][tid] = lstart + c0 + c1 + c2;
+    gdelta[tid] = hist_excl[(i64)tid * nblk + blockIdx.x] - lstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < kSteps; ++st) {  // (C) stable ranks, staged into LDS in digit order
+    const i64 i = wbase + st * 64 + lane;
+    const bool valid = i < n;
+    const unsigned d = (k[st] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+    const int pos = off[w][d];
+    if (valid && rank == 0) off[w][d] = pos + __builtin_popcountll(peers);
+    if (valid) {
+      s_key[pos + rank] = k[st];
+      s_val[pos + rank] = v[st];
+    }
+  }
+  __syncthreads();
+  const int nvalid = (int)((n - bbase < kBigChunk) ? (n - bbase) : kBigChunk);
+  for (int i = tid; i < nvalid; i += 256) {  // (D) coalesced copy-out: consecutive lanes, consecutive slots
+    const unsigned kk = s_key[i];
+    const i64 g = (i64)i + gdelta[(kk >> shift) & 255u];
+    key_out[g] = kk;
+    val_out[g] = s_val[i];
+  }
+}
+
 // tile_start[t] = first sorted entry whose tile id is >= t, for t in [0, n_tiles]
 __global__ void k_tile_bounds(const unsigned* key, i64 K, int n_tiles, int* tile_start) {
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -722,6 +808,56 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
     hipLaunchKernelGGL(k_box_sizes, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
                        (i64)n_gauss, width, height, box_size);
     GCP_HIP(hipGetLastError());
+  }
+  return GCP_OK;
+}
+
+size_t gcp_sort_workspace_bytes(int64_t n) {
+  const int64_t m = n > 0 ? n : 1;
+  const int64_t nblk = (m + kBigChunk - 1) / kBigChunk;
+  size_t b = 2 * align256((size_t)m * sizeof(unsigned));            // ping-pong key / payload
+  b += 2 * align256((size_t)(256 * nblk + 1) * sizeof(int));        // hist, hist_excl
+  b += gcp_scan_i32_workspace_bytes(256 * nblk);
+  return b;
+}
+
+int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
+                       void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || n > 0x7fffffffLL || key_bits < 1 || key_bits > 32) return GCP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GCP_OK;
+  if (!keys_in || !keys_out || !index_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_sort_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  const i64 nblk = (n + kBigChunk - 1) / kBigChunk;
+  char* p = (char*)ws;
+  unsigned* keyY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
+  unsigned* valY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
+  int* hist = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* hist_ex = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* sws = (int*)p;
+  unsigned* keyX = keys_out;
+  unsigned* valX = (unsigned*)index_out;
+  const int passes = (key_bits + 7) / 8;
+  const unsigned* ks = keys_in;
+  const unsigned* vs = nullptr;
+  for (int pass = 0; pass < passes; ++pass) {
+    const bool to_x = ((passes - 1 - pass) & 1) == 0;  // the last pass lands in the caller's buffers
+    unsigned* kd = to_x ? keyX : keyY;
+    unsigned* vd = to_x ? valX : valY;
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, (i64)n, shift, hist, (int)nblk);
+    GCP_HIP(hipGetLastError());
+    const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
+    if (st != GCP_OK) return st;
+    if (pass == 0)
+      hipLaunchKernelGGL((k_sort_scatter<true>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
+                         (const int*)hist_ex, (int)nblk);
+    else
+      hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
+                         (const int*)hist_ex, (int)nblk);
+    GCP_HIP(hipGetLastError());
+    ks = kd;
+    vs = vd;
   }
   return GCP_OK;
 }

@@ -224,3 +224,28 @@ def expand_rects(startpoint, endpoint, width, height, with_gaussian=False):
             "gcp_expand_rects",
         )
     return (rects, owner) if with_gaussian else rects
+
+
+def stable_sort_keys(keys, key_bits=None):
+    """Stable sort of non-negative int32 keys on the HIP library: returns (sorted_keys int32[n], index int32[n]) with
+    sorted_keys == keys[index] and equal keys in input order — `torch.sort(keys, stable=True)` as the reference needs
+    it for its pixel keys (gs_model.py:546-547), in ceil(key_bits/8) radix passes.  `key_bits` defaults to the bits of
+    keys.max() (one device->host read); pass it to stay asynchronous."""
+    k = _dev_tensor(keys, "keys", torch.int32)
+    _require(k.dim() == 1, "keys: expected a 1-D tensor")
+    n = k.numel()
+    dev = k.device
+    lib = _lib.load()
+    out_k = torch.empty_like(k)
+    out_i = torch.empty_like(k)
+    if n == 0:
+        return out_k, out_i
+    if key_bits is None:
+        mx = int(k.max().item())
+        _require(int(k.min().item()) >= 0, "keys: negative keys are not supported")
+        key_bits = max(1, mx.bit_length())
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.gcp_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_sort_pairs_u32(k.data_ptr(), n, int(key_bits), out_k.data_ptr(), out_i.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _stream(dev)), "gcp_sort_pairs_u32")
+    return out_k, out_i

@@ -331,3 +331,17 @@ def test_all_boxes_empty(device):
     assert float(img.abs().sum()) == 0.0
     grads = raster.blend_backward(bins, *args, img, torch.ones_like(img))
     assert all(float(g.abs().sum()) == 0.0 for g in grads)
+
+
+@pytest.mark.parametrize("n,hi", [(1, 5), (63, 3), (4096, 1 << 8), (4097, 1 << 16), (100003, 10_800_000), (3_000_017, 21_600_000),
+                                  (50_000, 1), (200_000, 2_000_000_000)])
+def test_stable_sort_keys_equals_torch_stable_sort(device, n, hi):
+    """The native (key, index) sort: same sorted keys AND the same permutation as torch.sort(stable=True)."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, hi + 1, (n,), generator=g, dtype=torch.int32)
+    want_k, want_i = torch.sort(keys, stable=True)
+    got_k, got_i = raster.stable_sort_keys(keys.to(device))
+    assert torch.equal(got_k.cpu(), want_k)
+    assert torch.equal(got_i.cpu().long(), want_i)

@@ -47,7 +47,6 @@ constexpr int kStage = 256;         // list entries staged per LDS round (forwar
 constexpr int kStageBwd = 32;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kGradVals = 9;        // per (tile, Gaussian) slot: go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
 constexpr int kRowVals = 7;         // per pixel row in LDS: go, gl0..2, S(c), S(c dx), S(c dx dx)   (dy is constant along a row)
-constexpr int kSortChunk = 2048;    // keys per radix block
 constexpr int kScanChunk = 2048;    // ints per prefix-sum block
 
 // sum over each 16-lane DPP row (= one pixel row of the tile); valid in lanes 15, 31, 47, 63
@@ -170,86 +169,26 @@ __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int 
     }
 }
 
-// stable LSD radix sort, 8-bit digit.  hist layout [digit][block] so one linear exclusive scan
-// yields, for every (digit, block), the first output slot of that block's keys of that digit.
-__global__ __launch_bounds__(256) void k_radix_hist(const unsigned* key, i64 K, int shift, int* hist, int nblk) {
-  __shared__ int h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
-  const i64 base = (i64)blockIdx.x * kSortChunk;
-  for (int i = threadIdx.x; i < kSortChunk; i += 256)
-    if (base + i < K) atomicAdd(&h[(key[base + i] >> shift) & 255u], 1);
-  __syncthreads();
-  hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
-}
-
-// Stable scatter of one 2048-key block.  Wave w owns keys [512w, 512w+512) of the block, so a digit's keys
-// of wave w go after those of waves < w: (A) every wave counts its digits, (B) an exclusive prefix over the
-// waves plus the block's global offset gives every (wave, digit) its first slot, (C) each wave ranks its keys
-// 64 at a time in order — peers with the same digit from 8 ballots, rank = earlier lanes among the peers —
-// touching only its own LDS row, so no block barrier inside the loop.  Deterministic: no atomics decide a slot.
-__global__ __launch_bounds__(256) void k_radix_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
-                                                        unsigned* val_out, i64 K, int shift, const int* hist_excl,
-                                                        int nblk) {
-  __shared__ int off[4][256];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int d = lane; d < 256; d += 64) off[w][d] = 0;
-  __syncthreads();
-  const i64 wbase = (i64)blockIdx.x * kSortChunk + (i64)w * (kSortChunk / 4);
-  constexpr int kSteps = kSortChunk / 4 / 64;
-  unsigned k[kSteps], v[kSteps];
-#pragma unroll
-  for (int st = 0; st < kSteps; ++st) {  // (A)
-    const i64 i = wbase + st * 64 + lane;
-    const bool valid = i < K;
-    k[st] = valid ? key[i] : 0u;
-    v[st] = valid ? val[i] : 0u;
-    if (valid) atomicAdd(&off[w][(k[st] >> shift) & 255u], 1);  // counts only: order-independent
-  }
-  __syncthreads();
-  {  // (B) thread d: exclusive prefix over the 4 waves + global offset of (digit d, this block)
-    int run = hist_excl[(i64)tid * nblk + blockIdx.x];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = off[j][tid]; off[j][tid] = run; run += c; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int st = 0; st < kSteps; ++st) {  // (C)
-    const i64 i = wbase + st * 64 + lane;
-    const bool valid = i < K;
-    const unsigned d = (k[st] >> shift) & 255u;
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    const int rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));  // earlier lanes first: stable
-    const int pos = off[w][d];
-    if (valid && rank == 0) off[w][d] = pos + __builtin_popcountll(peers);  // same wave: ordered after the read
-    if (valid) {
-      key_out[pos + rank] = k[st];
-      val_out[pos + rank] = v[st];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// General stable sort of (key, index) pairs for M-sized inputs (the pixel-key sort of the reference's
-// _create_alpha_brend, gs_model.py:546-547): same LSD passes, but 4096-key blocks whose output is first
-// arranged in LDS in digit order and then copied out, so every digit's run leaves the block as one
-// contiguous (coalesced) global write instead of 4-byte scatters.
+// Stable LSD radix sort of (key, payload) pairs, 8-bit digits — used for the (tile, Gaussian) entries of the
+// binning and, as gcp_sort_pairs_u32, for M-sized pixel-key arrays (the sort of the reference's
+// _create_alpha_brend, gs_model.py:546-547).  Per pass: per-block digit histogram laid out [digit][block], ONE
+// linear exclusive scan of it (= first output slot of every (digit, block)), then a stable scatter of 4096-key
+// blocks.  Inside a block wave w owns keys [1024w, 1024w+1024): (A) every wave counts its digits, (B) a prefix
+// over digits and waves gives every (wave, digit) its first slot, (C) each wave ranks its keys 64 at a time in
+// order — peers with the same digit from 8 ballots, rank = earlier lanes among the peers — and parks them in
+// LDS in digit order, (D) the block copies LDS out, so every digit run is one coalesced global write.
+// Deterministic: no atomic ever decides a slot.
 // ------------------------------------------------------------------------------------------
-constexpr int kBigChunk = 4096;
+constexpr int kSortChunk = 4096;    // keys per radix-sort block
 
 __global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk) {
   __shared__ int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const i64 base = (i64)blockIdx.x * kBigChunk;
+  const i64 base = (i64)blockIdx.x * kSortChunk;
 #pragma unroll 4
-  for (int i = threadIdx.x; i < kBigChunk; i += 256)
+  for (int i = threadIdx.x; i < kSortChunk; i += 256)
     if (base + i < n) atomicAdd(&h[(key[base + i] >> shift) & 255u], 1);
   __syncthreads();
   hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -259,17 +198,17 @@ template <bool FIRST>  // FIRST: the payload is the element's own index
 __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
                                                        unsigned* val_out, i64 n, int shift, const int* hist_excl,
                                                        int nblk) {
-  __shared__ unsigned s_key[kBigChunk];
-  __shared__ unsigned s_val[kBigChunk];
+  __shared__ unsigned s_key[kSortChunk];
+  __shared__ unsigned s_val[kSortChunk];
   __shared__ int off[4][256];   // (A) per-wave digit counts -> (B) first LDS slot of (wave, digit)
   __shared__ int gdelta[256];   // global slot = LDS slot + gdelta[digit]
   __shared__ int s_w[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int d = lane; d < 256; d += 64) off[w][d] = 0;
   __syncthreads();
-  const i64 bbase = (i64)blockIdx.x * kBigChunk;
-  const i64 wbase = bbase + (i64)w * (kBigChunk / 4);
-  constexpr int kSteps = kBigChunk / 4 / 64;  // 16
+  const i64 bbase = (i64)blockIdx.x * kSortChunk;
+  const i64 wbase = bbase + (i64)w * (kSortChunk / 4);
+  constexpr int kSteps = kSortChunk / 4 / 64;  // 16
   unsigned k[kSteps], v[kSteps];
 #pragma unroll
   for (int st = 0; st < kSteps; ++st) {  // (A)
@@ -312,7 +251,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
     }
   }
   __syncthreads();
-  const int nvalid = (int)((n - bbase < kBigChunk) ? (n - bbase) : kBigChunk);
+  const int nvalid = (int)((n - bbase < kSortChunk) ? (n - bbase) : kSortChunk);
   for (int i = tid; i < nvalid; i += 256) {  // (D) coalesced copy-out: consecutive lanes, consecutive slots
     const unsigned kk = s_key[i];
     const i64 g = (i64)i + gdelta[(kk >> shift) & 255u];
@@ -719,12 +658,12 @@ int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n
   unsigned *ks = keyA, *vs = valA, *kd = keyB, *vd = valB;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_radix_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, K, shift, hist, (int)nblk);
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks, K, shift, hist, (int)nblk);
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
     if (st != GCP_OK) return st;
-    hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, K, shift,
-                       (const int*)hist_ex, (int)nblk);
+    hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks,
+                       (const unsigned*)vs, kd, vd, K, shift, (const int*)hist_ex, (int)nblk);
     GCP_HIP(hipGetLastError());
     unsigned* t;
     t = ks; ks = kd; kd = t;
@@ -814,7 +753,7 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
 
 size_t gcp_sort_workspace_bytes(int64_t n) {
   const int64_t m = n > 0 ? n : 1;
-  const int64_t nblk = (m + kBigChunk - 1) / kBigChunk;
+  const int64_t nblk = (m + kSortChunk - 1) / kSortChunk;
   size_t b = 2 * align256((size_t)m * sizeof(unsigned));            // ping-pong key / payload
   b += 2 * align256((size_t)(256 * nblk + 1) * sizeof(int));        // hist, hist_excl
   b += gcp_scan_i32_workspace_bytes(256 * nblk);
@@ -828,7 +767,7 @@ int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uin
   if (n == 0) return GCP_OK;
   if (!keys_in || !keys_out || !index_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_sort_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
-  const i64 nblk = (n + kBigChunk - 1) / kBigChunk;
+  const i64 nblk = (n + kSortChunk - 1) / kSortChunk;
   char* p = (char*)ws;
   unsigned* keyY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
   unsigned* valY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));

@@ -31,40 +31,53 @@ BYTES_FWD, BYTES_BWD = 12, 20  # algorithmic bytes per pair
 
 
 def cpu_baseline(p, sample_pairs):
-    """Oracle (sequential C port of the reference kernels) on the first groups of the pair list."""
+    """Oracle (C port of the reference kernels, oracle/gcp_oracle.c) on the first groups of the pair list, on the host
+    cores of this box: OpenMP over pixel groups with up to 16 threads (one GPU's CPU share) = the headline figure,
+    plus the single-thread time on a quarter of the sample and the pure-PyTorch torch.cumprod path."""
     import torch
 
     from oracle import c_oracle as co
-
-    inv_len = p.inv_len.cpu()
-    g = int(torch.searchsorted(inv_len, torch.tensor(sample_pairs, dtype=inv_len.dtype)).item())
-    g = max(1, min(g, inv_len.numel()))
-    s = int(inv_len[g - 1].item())
-    x, key, inv, go = (t[:s].cpu().contiguous() for t in (p.x, p.key, p.inv, p.grad_out))
-    il = inv_len[:g].contiguous()
-    co.cumprod_forward(x[:1024].contiguous(), key[:1024].contiguous())  # load the library
-    t0 = time.perf_counter()
-    y = co.cumprod_forward(x, key)
-    t1 = time.perf_counter()
-    co.cumprod_backward(x, y, go, inv, il)
-    t2 = time.perf_counter()
-    # the "pure-PyTorch torch.cumprod path" of BASELINE.json (per-group torch.cumprod), forward only, smaller sample
     from oracle import torch_path as tp
 
-    g8 = int(torch.searchsorted(inv_len, torch.tensor(min(8_000_000, s), dtype=inv_len.dtype)).item())
-    s8 = int(inv_len[max(g8, 1) - 1].item())
+    inv_len = p.inv_len.cpu()
+
+    def prefix(pairs):
+        g = int(torch.searchsorted(inv_len, torch.tensor(pairs, dtype=inv_len.dtype)).item())
+        g = max(1, min(g, inv_len.numel()))
+        return g, int(inv_len[g - 1].item())
+
+    g, s = prefix(sample_pairs)
+    x, key, inv, go = (t[:s].cpu().contiguous() for t in (p.x, p.key, p.inv, p.grad_out))
+    il = inv_len[:g].contiguous()
+    threads = max(1, min(16, os.cpu_count() or 1, co.max_threads()))
+    co.cumprod_forward_mt(x[: il[0]].contiguous(), il[:1].contiguous(), threads)  # load the library, start the thread pool
+    t0 = time.perf_counter()
+    y = co.cumprod_forward_mt(x, il, threads)
+    t1 = time.perf_counter()
+    co.cumprod_backward_mt(x, y, go, inv, il, threads)
+    t2 = time.perf_counter()
+    # single thread, a quarter of the sample
+    g1, s1 = prefix(max(1, sample_pairs // 4))
+    x1, k1, i1, go1, il1 = x[:s1].contiguous(), key[:s1].contiguous(), inv[:s1].contiguous(), go[:s1].contiguous(), inv_len[:g1].contiguous()
     t3 = time.perf_counter()
-    tp.grouped_cumprod(x[:s8].contiguous(), key[:s8].contiguous())
+    y1 = co.cumprod_forward(x1, k1)
+    co.cumprod_backward(x1, y1, go1, i1, il1)
     t4 = time.perf_counter()
+    # the "pure-PyTorch torch.cumprod path" of BASELINE.json (per-group torch.cumprod), forward only
+    g8, s8 = prefix(min(8_000_000, s))
+    t5 = time.perf_counter()
+    tp.grouped_cumprod(x[:s8].contiguous(), key[:s8].contiguous())
+    t6 = time.perf_counter()
     return {
         "value": s / (t2 - t0),
         "unit": "pairs/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
-        "sample": f"first {g} pixel groups = {s} pairs of the same pair list; oracle/gcp_oracle.c "
-        f"(sequential fp32, literal O(L^2) backward loop of the reference); fwd {1e3*(t1-t0):.1f} ms, "
+        "sample": f"first {g} pixel groups = {s} pairs of the same pair list; oracle/gcp_oracle.c (fp32, every group scanned "
+        f"left to right, literal O(L^2) backward loop of the reference), OpenMP over groups; fwd {1e3*(t1-t0):.1f} ms, "
         f"bwd {1e3*(t2-t1):.1f} ms; host has {os.cpu_count()} cpus",
-        "torch_cumprod_path_forward": {"value": s8 / (t4 - t3), "unit": "pairs/s", "threads": torch.get_num_threads(),
+        "single_thread": {"value": s1 / (t4 - t3), "unit": "pairs/s", "cores": 1, "sample": f"{s1} pairs"},
+        "torch_cumprod_path_forward": {"value": s8 / (t6 - t5), "unit": "pairs/s", "threads": torch.get_num_threads(),
                                        "sample": f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"},
     }
 

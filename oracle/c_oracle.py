@@ -15,7 +15,7 @@ def build(force=False):
     """gcc -O2 -ffp-contract=off: strict left-to-right fp32, no fused multiply-add."""
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         subprocess.run(
-            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _SO, _SRC], check=True
+            ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", _SO, _SRC], check=True
         )
     return _SO
 
@@ -105,3 +105,21 @@ def groups_from_key(key):
     starts = torch.nonzero(head).flatten()
     inv_len = torch.cat([starts[1:], torch.tensor([n])]).to(torch.int32)
     return inv, inv_len
+
+
+def max_threads():
+    return int(_load().oracle_max_threads())
+
+
+def cumprod_forward_mt(x, inv_len, threads):
+    """Same results as cumprod_forward, groups spread over `threads` OpenMP threads (bench.py's CPU baseline)."""
+    y = torch.empty_like(x)
+    _load().oracle_cumprod_forward_mt(_f32(x), _i32(inv_len), _f32(y), _n(inv_len), ctypes.c_int(threads))
+    return y
+
+
+def cumprod_backward_mt(param, param_cumprod, grad_out, inv, inv_len, threads):
+    g = torch.empty_like(param)
+    _load().oracle_cumprod_backward_mt(_f32(param), _f32(param_cumprod), _f32(grad_out), _i32(inv), _f32(g), _i32(inv_len),
+                                       _n(param), ctypes.c_int(threads))
+    return g

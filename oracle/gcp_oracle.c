@@ -11,7 +11,8 @@
  *     worked example in uitility.py:383-393), tests/test_oracle.py;
  *   - the reference's cuda_kernel/grouped_cum{prod,sum}_forward.cu compiled
  *     unmodified for the host (rocThrust CPP backend) into oracle/_ref/, both
- *     live (tests/test_oracle_vs_ref.py, only where /root/reference exists)
+ *     live (tests/test_oracle.py::test_oracle_vs_live_reference_host_build,
+ *     only where oracle/_ref/ exists)
  *     and through committed golden vectors (tests/golden/).
  *
  * Every function is strictly sequential, left to right, in fp32 — the
@@ -121,5 +122,44 @@ void oracle_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t
   for (int64_t i = n - 2; i >= 0; --i) {
     acc = (key[i] == key[i + 1]) ? acc + x[i] : x[i];
     y[i] = acc;
+  }
+}
+
+/*
+ * Multi-threaded forms for the CPU baseline of bench.py (OpenMP over groups / elements; every group is still
+ * scanned sequentially left to right in fp32, so the results are bit-identical to the functions above).
+ * `group_end` = exclusive end offset per group (the reference's inv_len, cuda_test.py:27).
+ */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_max_threads(void) { return omp_get_max_threads(); }
+#else
+int oracle_max_threads(void) { return 1; }
+#endif
+
+void oracle_cumprod_forward_mt(const float* x, const int32_t* group_end, float* y, int64_t n_groups, int threads) {
+  (void)threads;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads)
+  for (int64_t g = 0; g < n_groups; ++g) {
+    const int64_t b = g ? group_end[g - 1] : 0, e = group_end[g];
+    float acc = 1.0f;
+    for (int64_t i = b; i < e; ++i) {
+      acc = (i == b) ? x[i] : acc * x[i];
+      y[i] = acc;
+    }
+  }
+}
+
+void oracle_cumprod_backward_mt(const float* param, const float* param_cumprod, const float* grad_out,
+                                const int32_t* inv, float* grad_in, const int32_t* inv_len, int64_t n, int threads) {
+  (void)threads;
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(threads)
+  for (int64_t idx = 0; idx < n; ++idx) {  /* reference: grouped_cumprod_backward.cu:18-29, one "thread" per idx */
+    const int32_t gid = inv[idx];
+    const int64_t i_max = inv_len[gid];
+    float val = 0.0f;
+    const float param_idx = (param[idx] != 0.0f) ? param[idx] : 1e-8f;
+    for (int64_t i = idx; i < i_max; ++i) val += grad_out[i] * (param_cumprod[i] / param_idx);
+    grad_in[idx] = val;
   }
 }

@@ -201,3 +201,16 @@ def test_reference_backward_breaks_when_a_suffix_sum_is_exactly_zero():
     img, gv, go, gl = dr.render_with_grads(g("start"), g("end"), g("mean"), g("vinv"), g("opacity"), g("l_d"), w, h, g("wimg"))
     torch.testing.assert_close(img.float(), g("image"), atol=1e-5, rtol=1e-5)
     assert (go.float() - g("grad_opacity")).abs().max() > 0.1  # the reference's own gradient is off by O(1)
+
+
+def test_multithreaded_oracle_is_bit_identical():
+    """bench.py's CPU baseline uses the OpenMP forms; they must give exactly the single-thread results."""
+    n = 200_000
+    key, x = make_keys(n, "mixed", 12), make_values(n, 12)
+    inv, inv_len = co.groups_from_key(key)
+    go = make_values(n, 13, "normal")
+    y1 = co.cumprod_forward(x, key)
+    assert torch.equal(co.cumprod_forward_mt(x, inv_len, 4), y1)
+    g1 = co.cumprod_backward(x, y1, go, inv, inv_len)
+    assert torch.equal(co.cumprod_backward_mt(x, y1, go, inv, inv_len, 4), g1)
+    assert co.max_threads() >= 1

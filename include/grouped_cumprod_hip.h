@@ -219,6 +219,14 @@ size_t gcp_sort_workspace_bytes(int64_t n);
 int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out,
                        int32_t* index_out, void* ws, size_t ws_bytes, void* stream);
 
+/* The index plumbing of _create_alpha_brend around the scan, with the int32 permutation of gcp_sort_pairs_u32:
+ * gcp_gather_f32: dst[i] = src[index[i]] (gs_model.py:548); gcp_unsort_finish: full[index[i]] = inclusive[i] / x_i
+ * (mode 0, gs_model.py:562) or inclusive[i] - x_i (mode 1, :564) with x_i = sorted_x[i], keep[index[i]] =
+ * (inclusive[i] != 0) (gs_model.py:560) — the un-sort (:555) fused with the steps that follow the compaction. */
+int gcp_gather_f32(const float* src, const int32_t* index, float* dst, int64_t n, void* stream);
+int gcp_unsort_finish(const float* inclusive, const float* sorted_x, const int32_t* index, float* full,
+                      uint8_t* keep, int64_t n, int32_t mode, void* stream);
+
 /* The reference's Gaussian-major rect list (Utilities.make_rect_points_parallel, uitility.py:336-366;
  * _create_rects, gs_model.py:480-482) for callers that still want it: box sizes (clamped to the image), then —
  * given their exclusive prefix sum box_off[N+1] — rects_xy int32[M,2] and optionally the owning Gaussian of

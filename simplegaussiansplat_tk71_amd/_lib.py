@@ -56,6 +56,8 @@ SIGNATURES = {
         ctypes.c_int,
         [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p, _i64] + [_c_void_p] * 8 + [_c_void_p, _sz, _c_void_p],
     ),
+    "gcp_gather_f32": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p]),
+    "gcp_unsort_finish": (ctypes.c_int, [_c_void_p] * 5 + [_i64, _i32, _c_void_p]),
     "gcp_sort_workspace_bytes": (_sz, [_i64]),
     "gcp_sort_pairs_u32": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_box_sizes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p]),

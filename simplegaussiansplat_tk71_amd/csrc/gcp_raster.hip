@@ -550,6 +550,27 @@ __global__ void k_expand_rects(const int* start, const int* end, const int* box_
   if (pair_gauss) pair_gauss[i] = (int)lo;
 }
 
+// ---- the index plumbing around the scan in _create_alpha_brend (gs_model.py:548, :555-564) --------------
+// sorted values: dst[i] = src[index[i]]   (gs_model.py:548 `anti_opacity[index]`), int32 permutation
+__global__ void k_gather_f32(const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst, i64 n) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[index[i]];
+}
+// un-sort + the two element-wise steps that follow the compaction, fused (they commute with it):
+//   full[index[i]] = inclusive[i] / self  (mode 0, gs_model.py:562)  or  inclusive[i] - self  (mode 1, :564)
+//   keep[index[i]] = inclusive[i] != 0                                  (gs_model.py:560, :575-578)
+// where self = sorted_x[i] is the pair's own input value (= anti_opacity[index[i]]).
+__global__ void k_unsort_finish(const float* __restrict__ incl, const float* __restrict__ sorted_x,
+                                const int* __restrict__ index, float* __restrict__ full, unsigned char* __restrict__ keep,
+                                i64 n, int mode) {
+  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = incl[i], x = sorted_x[i];
+  const int o = index[i];
+  full[o] = mode == 0 ? v / x : v - x;
+  keep[o] = v != 0.0f ? 1 : 0;
+}
+
 __global__ void k_box_sizes(const int* start, const int* end, i64 n, int W, int H, int* size) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -748,6 +769,26 @@ int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_
                        (i64)n_gauss, width, height, box_size);
     GCP_HIP(hipGetLastError());
   }
+  return GCP_OK;
+}
+
+int gcp_gather_f32(const float* src, const int32_t* index, float* dst, int64_t n, void* stream_) {
+  if (n < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GCP_OK;
+  if (!src || !index || !dst) return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, src, index, dst, (i64)n);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_unsort_finish(const float* inclusive, const float* sorted_x, const int32_t* index, float* full, uint8_t* keep,
+                      int64_t n, int32_t mode, void* stream_) {
+  if (n < 0 || (mode != 0 && mode != 1)) return GCP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GCP_OK;
+  if (!inclusive || !sorted_x || !index || !full || !keep) return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_unsort_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, inclusive, sorted_x,
+                     index, full, keep, (i64)n, mode);
+  GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 

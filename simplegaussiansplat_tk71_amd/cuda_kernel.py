@@ -19,7 +19,10 @@ Deliberate differences from the reference, all result-preserving:
     gcp_sort_pairs_u32: only the significant key bits, int32 payload, coalesced scatters;
     bit-identical to torch.sort(stable=True) and 1.7x faster at 1.6e8 keys).
   * the un-sort `output[torch.argsort(index)]` (gs_model.py:555, a second radix
-    sort) is done as the equivalent scatter `unsorted[index] = output`.
+    sort) is the equivalent scatter through the permutation, fused in ONE kernel
+    (gcp_unsort_finish) with the `/ self` or `- self` step and the `!= 0` test — those
+    commute with the compaction that the reference applies first (:560-564); the gather
+    (:548) uses the int32 permutation directly (gcp_gather_f32).
   * grad_cumsum's flip / scan / flip is one reverse scan on the same sorted keys.
 """
 import torch
@@ -100,18 +103,6 @@ def unique(rects):
         return rects[:, 1] * 10000 + rects[:, 0]
 
 
-def _stable_sort(inv):
-    """(sorted keys int32, permutation int64) of the pixel keys: the library's stable radix sort."""
-    sorted_inv, index = _raster.stable_sort_keys(inv.contiguous())
-    return sorted_inv, index.long()
-
-
-def _mask_zero_T(T):
-    # reference: gs_model.py:575-578
-    mask = T != 0
-    return [T[mask], mask]
-
-
 def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None):
     """Per-pixel exclusive transmittance (flag="cumprod") or exclusive prefix sum
     (flag="cumsum") of `anti_opacity`, returned in the ORIGINAL pair order.
@@ -123,25 +114,32 @@ def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None):
     """
     with torch.no_grad():
         inv = unique(rects)
-        sorted_inv, index = _stable_sort(inv)
-        sorted_anti_opacity = anti_opacity[index]
-        output = torch.zeros_like(sorted_anti_opacity)
-        if flag == "cumprod":
-            _ext.grouped_cumprod_forward(sorted_anti_opacity, sorted_inv, output)
-        elif flag == "cumsum":
-            _ext.grouped_cumsum_forward(sorted_anti_opacity, sorted_inv, output)
-        unsorted = torch.empty_like(output)
-        unsorted[index] = output  # == output[torch.argsort(index)]
-        output = unsorted
-        if cutting_number:
-            output = output[cutting_number:]
-            anti_opacity = anti_opacity[cutting_number:]
-        output, mask = _mask_zero_T(output)
-        if flag == "cumprod":
-            output = output / anti_opacity[mask]
-        elif flag == "cumsum":
-            output = output - anti_opacity[mask]
-        return [output, mask]
+        sorted_inv, index = _raster.stable_sort_keys(inv.contiguous())  # int32 permutation
+        return _scan_unsort_compact(sorted_inv, index, anti_opacity, flag, cutting_number)
+
+
+def _scan_unsort_compact(sorted_key, index, anti_opacity, flag, cutting_number=None):
+    """Everything of _create_alpha_brend after the sort (gs_model.py:548-566) on the HIP library: gather, grouped
+    scan, then ONE kernel for un-sort + (/ self | - self) + the != 0 test; only the final compaction is a torch op.
+    flag "cumsum_reverse" is grad_cumsum's suffix form (gs_model.py:716-722), whose carry rows sit at the END."""
+    if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
+        raise ValueError(flag)
+    anti_opacity = anti_opacity.contiguous()
+    sorted_x = _raster.gather_f32(anti_opacity, index)
+    output = torch.empty_like(sorted_x)
+    if flag == "cumprod":
+        _ext.grouped_cumprod_forward(sorted_x, sorted_key, output)
+    elif flag == "cumsum":
+        _ext.grouped_cumsum_forward(sorted_x, sorted_key, output)
+    else:
+        _ext.grouped_cumsum_reverse(sorted_x, sorted_key, output)
+    full, keep = _raster.unsort_finish(output, sorted_x, index, 0 if flag == "cumprod" else 1)
+    if cutting_number:
+        if flag == "cumsum_reverse":
+            full, keep = full[: full.numel() - cutting_number], keep[: keep.numel() - cutting_number]
+        else:
+            full, keep = full[cutting_number:], keep[cutting_number:]
+    return [full[keep], keep]
 
 
 create_alpha_blend = create_alpha_brend  # spelling alias
@@ -156,21 +154,7 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
     with torch.no_grad():
         bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
         pl = _raster.pixel_lists(bins, startpoint, endpoint)
-        index = pl.pair_index.long()
-        sorted_anti_opacity = anti_opacity[index]
-        output = torch.zeros_like(sorted_anti_opacity)
-        if flag == "cumprod":
-            _ext.grouped_cumprod_forward(sorted_anti_opacity, pl.pair_key, output)
-        elif flag == "cumsum":
-            _ext.grouped_cumsum_forward(sorted_anti_opacity, pl.pair_key, output)
-        unsorted = torch.empty_like(output)
-        unsorted[index] = output
-        output, mask = _mask_zero_T(unsorted)
-        if flag == "cumprod":
-            output = output / anti_opacity[mask]
-        elif flag == "cumsum":
-            output = output - anti_opacity[mask]
-        return [output, mask]
+        return _scan_unsort_compact(pl.pair_key, pl.pair_index, anti_opacity, flag)
 
 
 def grad_cumsum(rects, grad, cutting_number=None):
@@ -180,23 +164,13 @@ def grad_cumsum(rects, grad, cutting_number=None):
     Flipping a stably sorted list and summing forward equals summing backward on the
     un-flipped list, so this runs one reverse scan instead.  `cutting_number` counts
     rows at the START of the flipped arrays, i.e. the LAST rows of the inputs
-    (gs_model.py:636 appends the carry rows at the end before the flip).
+    (gs_model.py:636 appends the carry rows at the end before the flip).  The mask is
+    returned in ORIGINAL order (the reference leaves it flipped).
     """
     with torch.no_grad():
         inv = unique(rects)
-        sorted_inv, index = _stable_sort(inv)
-        sorted_grad = grad[index]
-        output = torch.zeros_like(sorted_grad)
-        _ext.grouped_cumsum_reverse(sorted_grad, sorted_inv, output)
-        unsorted = torch.empty_like(output)
-        unsorted[index] = output
-        output = unsorted
-        if cutting_number:
-            output = output[: output.numel() - cutting_number]
-            grad = grad[: grad.numel() - cutting_number]
-        mask = output != 0
-        output = output[mask] - grad[mask]
-        return [output, mask]
+        sorted_inv, index = _raster.stable_sort_keys(inv.contiguous())
+        return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
 
 
 def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
@@ -205,14 +179,7 @@ def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
     with torch.no_grad():
         bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
         pl = _raster.pixel_lists(bins, startpoint, endpoint)
-        index = pl.pair_index.long()
-        sorted_grad = grad[index]
-        output = torch.zeros_like(sorted_grad)
-        _ext.grouped_cumsum_reverse(sorted_grad, pl.pair_key, output)
-        unsorted = torch.empty_like(output)
-        unsorted[index] = output
-        mask = unsorted != 0
-        return [unsorted[mask] - grad[mask], mask]
+        return _scan_unsort_compact(pl.pair_key, pl.pair_index, grad, "cumsum_reverse")
 
 
 class custom_autograd_grouped_cumprod(torch.autograd.Function):

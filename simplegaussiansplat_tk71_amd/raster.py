@@ -249,3 +249,27 @@ def stable_sort_keys(keys, key_bits=None):
         _lib.check(lib.gcp_sort_pairs_u32(k.data_ptr(), n, int(key_bits), out_k.data_ptr(), out_i.data_ptr(), ws.data_ptr(),
                                           ws.numel(), _stream(dev)), "gcp_sort_pairs_u32")
     return out_k, out_i
+
+
+def gather_f32(src, index):
+    """src[index] for an int32 permutation (gs_model.py:548)."""
+    src = _dev_tensor(src, "src", torch.float32)
+    index = _dev_tensor(index, "index", torch.int32)
+    dst = torch.empty(index.numel(), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().gcp_gather_f32(src.data_ptr(), index.data_ptr(), dst.data_ptr(), index.numel(), _stream(src.device)),
+                   "gcp_gather_f32")
+    return dst
+
+
+def unsort_finish(inclusive, sorted_x, index, mode):
+    """Un-sort fused with `/ self` (mode 0) or `- self` (mode 1) and the `!= 0` test: -> (full f32[n], keep bool[n]) in the
+    original pair order (gs_model.py:555-564)."""
+    dev = inclusive.device
+    n = inclusive.numel()
+    full = torch.empty(n, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().gcp_unsort_finish(inclusive.data_ptr(), sorted_x.data_ptr(), index.data_ptr(), full.data_ptr(),
+                                                 keep.data_ptr(), n, int(mode), _stream(dev)), "gcp_unsort_finish")
+    return full, keep.view(torch.bool)

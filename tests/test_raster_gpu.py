@@ -55,7 +55,7 @@ def test_function_vs_reference_golden(device, name):
 
 
 @pytest.mark.parametrize("n_gauss,w,h,mh,seed,one", [(1, 8, 8, 2, 1, 0), (40, 33, 17, 4, 2, 0), (400, 100, 70, 9, 3, 0),
-                                                      (300, 64, 64, 20, 4, 0), (250, 50, 40, 6, 5, 7)])
+                                                      (300, 64, 64, 20, 4, 0), (250, 50, 40, 6, 5, 7), (2500, 255, 191, 10, 6, 0)])
 def test_function_vs_dense_oracle(device, n_gauss, w, h, mh, seed, one):
     """Random scenes incl. boxes spanning many tiles and (one=7) opacity-1 Gaussians whose centre pixel has an
     inclusive product of exactly 0 (dropped pair, gs_model.py:560)."""

@@ -273,3 +273,32 @@ def unsort_finish(inclusive, sorted_x, index, mode):
         _lib.check(_lib.load().gcp_unsort_finish(inclusive.data_ptr(), sorted_x.data_ptr(), index.data_ptr(), full.data_ptr(),
                                                  keep.data_ptr(), n, int(mode), _stream(dev)), "gcp_unsort_finish")
     return full, keep.view(torch.bool)
+
+
+def render_cameras(cameras, n_streams=3):
+    """Forward-render several cameras of one batch (the reference loops over them one after the other,
+    gs_model.py:402-449) on `n_streams` HIP streams: the binning of one camera has to hand its entry count to the
+    host (a per-STREAM synchronisation, like the reference's `.item()`), and while that stream waits the other
+    streams keep the GPU busy with their blends.  `cameras`: iterable of dicts with keys start, end, mean, vinv,
+    opacity, l_d, width, height.  Returns the list of images [(H+1, W+1, 3)] in input order."""
+    cameras = list(cameras)
+    if not cameras:
+        return []
+    dev = cameras[0]["start"].device
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, min(n_streams, len(cameras))))]
+    cur = torch.cuda.current_stream(dev)
+    for st in streams:
+        st.wait_stream(cur)
+    images = [None] * len(cameras)
+    for i, c in enumerate(cameras):
+        st = streams[i % len(streams)]
+        with torch.cuda.stream(st):
+            bins = bin_tiles(c["start"], c["end"], c["width"], c["height"])
+            images[i] = blend_forward(bins, c["start"], c["end"], c["mean"], c["vinv"], c["opacity"], c["l_d"])
+            for t in (c["start"], c["end"], c["mean"], c["vinv"], c["opacity"], c["l_d"]):
+                t.record_stream(st)
+    for st in streams:
+        cur.wait_stream(st)
+    for img in images:
+        img.record_stream(cur)
+    return images

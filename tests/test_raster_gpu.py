@@ -345,3 +345,20 @@ def test_stable_sort_keys_equals_torch_stable_sort(device, n, hi):
     got_k, got_i = raster.stable_sort_keys(keys.to(device))
     assert torch.equal(got_k.cpu(), want_k)
     assert torch.equal(got_i.cpu().long(), want_i)
+
+
+def test_render_cameras_on_two_streams_equals_sequential(device):
+    from simplegaussiansplat_tk71_amd import raster
+
+    cams = []
+    for seed in range(5):
+        sc = make_scene(400 + 50 * seed, 100, 80, 8, 80 + seed)
+        cams.append({k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()})
+    seq = []
+    for c in cams:
+        bins = raster.bin_tiles(c["start"], c["end"], c["width"], c["height"])
+        seq.append(raster.blend_forward(bins, c["start"], c["end"], c["mean"], c["vinv"], c["opacity"], c["l_d"]))
+    par = raster.render_cameras(cams, n_streams=2)
+    torch.cuda.synchronize()
+    for a, b in zip(seq, par):
+        assert torch.equal(a, b)

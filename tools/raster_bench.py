@@ -51,6 +51,11 @@ def main():
         tot += med
         print(f"{k:16s} median {med*1e3:9.1f} us  min {mn*1e3:9.1f} us   {m/med/1e6:8.2f} Gpairs/s")
     print(f"bin+fwd+bwd {tot*1e3:.1f} us -> {m/tot/1e6:.2f} Gpairs/s end to end (whole Function)")
+    # a batch of cameras (the reference renders them one after the other, gs_model.py:402-449): 1 vs 2 streams
+    cams = [sc] * 6
+    for ns in (1, 2, 3):
+        t, _ = timeit(lambda: raster.render_cameras(cams, n_streams=ns), iters=5, warmup=2)
+        print(f"render 6 cameras (bin + forward) on {ns} stream(s): {t:.3f} ms")
 
 
 if __name__ == "__main__":

@@ -171,10 +171,17 @@ def main():
                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus}"
             )
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; GCP_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to rehearse the N > 1 control
+    # flow on a one-GPU box
+    backend = os.environ.get("GCP_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the few collective operands live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     # this rank's band of the frame; bands are independent pair lists (no exchange on the scan path)
     if args.workload == "cfg5band":
@@ -225,7 +232,7 @@ def main():
     t_bwd = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps * 1e-3
     fallback = gc.last_fallback_tiles(dev)
 
-    stats = torch.tensor([elapsed, float(m)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(m)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -237,7 +244,7 @@ def main():
 
     # frame assembly / gradient distribution (outside the timed region; the scan path has no collective)
     gather_ms = scatter_ms = None
-    if world > 1 and os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1":
+    if world > 1 and backend == "nccl" and os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1":
         try:
             from simplegaussiansplat_tk71_amd import sharding
 

@@ -208,8 +208,14 @@ class GS_dataset(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         return [self.P[idx], self.K[idx], self.wh[idx], self.image_sample[idx]]
 
-    def get_camera_extent(self):
+    def get_camera_extent(self, reference_translation=False):
+        """Largest distance of a camera from the mean camera position.  The reference measures it on the translation
+        column of [R|t] (gs_model.py:23-30) — the world origin in camera coordinates, which is the same point for every
+        camera that looks at the origin; the camera centres -R^T t are used here (`reference_translation=True`
+        restores the reference's quantity)."""
         t = self.P[:, :, 3]
+        if not reference_translation:
+            t = -(self.P[:, :, 0:3].transpose(1, 2) @ t[:, :, None]).squeeze(-1)
         return torch.max((t.mean(dim=0)[None] - t).norm(dim=1)).item()
 
 
@@ -340,6 +346,8 @@ class GS_model_with_param(torch.nn.Module):
                 cam["boxsize"], batch, cam["startpoint"], cam["endpoint"], cam["mean"], cam["variance_inverse"],
                 cam["opacity"], cam["l_d"], width, height))
             names.append(name)
+        if not images:
+            raise RuntimeError("no camera of the batch sees any Gaussian")  # the reference fails in torch.stack (:454)
         out = torch.stack(images, dim=0)[:, 1:, 1:, :]
         h, w = int(height), int(width)
         out = out.reshape(-1, 3, h, w) if self.reference_layout else out.permute(0, 3, 1, 2).contiguous()

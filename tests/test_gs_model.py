@@ -171,3 +171,14 @@ def test_colmap_reads_the_reference_scene():
     assert {(c["width"], c["height"]) for c in cams.values()} == {(640, 427)}
     pts = colmap_io.read_points3d("/root/reference/colmap/sparse/0/points3D.bin")
     assert pts["xyz"].shape == (10409, 3) and np.isfinite(pts["xyz"]).all() and len(np.unique(pts["id"])) == 10409
+
+
+def test_camera_extent_uses_camera_centres():
+    # two cameras at (+-2, 0, 0) looking at the origin: centres 4 apart, translation columns identical
+    R0 = torch.tensor([[0.0, 0, 1], [0, 1, 0], [-1, 0, 0]])  # forward = -x
+    R1 = torch.tensor([[0.0, 0, -1], [0, 1, 0], [1, 0, 0]])  # forward = +x
+    P = torch.stack([torch.cat([R0, -(R0 @ torch.tensor([2.0, 0, 0]))[:, None]], 1), torch.cat([R1, -(R1 @ torch.tensor([-2.0, 0, 0]))[:, None]], 1)])
+    data = gm.GS_dataset(P, torch.eye(3).expand(2, 3, 3), torch.tensor([[8.0, 8.0]] * 2), ["a", "b"])
+    assert len(data) == 2 and data[1][3] == "b"
+    assert data.get_camera_extent() == pytest.approx(2.0)
+    assert data.get_camera_extent(reference_translation=True) == pytest.approx(0.0, abs=1e-6)

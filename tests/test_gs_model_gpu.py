@@ -102,4 +102,4 @@ def test_training_loop_learns_and_densifies(device):
     n = model.mean.shape[0]
     assert model.variance_q.shape[0] == n and model.color.shape[0] == n and model.mean_grads_iter.shape[0] == n
     model.reset_opacity(0.01)
-    assert float(torch.sigmoid(model.opacity).max()) <= 0.01 + 1e-6
+    assert float(torch.sigmoid(model.opacity.detach()).max()) <= 0.01 + 1e-6

@@ -47,13 +47,19 @@ def test_forward_matches_reference_model_images(name, device):
     h, wd = int(w["wh"][0, 1]), int(w["wh"][0, 0])
     torch.testing.assert_close(proper.permute(0, 2, 3, 1).reshape(-1, 3, h, wd), images, atol=0, rtol=0)
     # the device projection gives the integers the reference computed on the CPU
-    cams, _, _ = gm.camera_inputs(w["mean"], w["variance_q"], w["variance_scale"], w["opacity"], w["color"], w["P"], w["K"], w["wh"], TILE_LOGIT)
-    for c, cam in enumerate(cams):
-        for mine, theirs in (("startpoint", "startpoint"), ("endpoint", "endpoint"), ("mean", "mean_pixel"), ("boxsize", "boxsize")):
-            assert np.array_equal(cam[mine].cpu().numpy(), z[f"{name}/cam{c}/{theirs}"]), (c, mine)
+    for fused in (True, False):
+        cams, _, _ = gm.camera_inputs(w["mean"], w["variance_q"], w["variance_scale"], w["opacity"], w["color"], w["P"], w["K"], w["wh"],
+                                      TILE_LOGIT, fused=fused)
+        for c, cam in enumerate(cams):
+            for mine, theirs in (("startpoint", "startpoint"), ("endpoint", "endpoint"), ("mean", "mean_pixel"), ("boxsize", "boxsize")):
+                got, want = cam[mine].cpu().numpy(), z[f"{name}/cam{c}/{theirs}"]
+                assert got.dtype == want.dtype and np.array_equal(got, want), (fused, c, mine)
+            for mine, theirs in (("variance_inverse", "variance_inverse"), ("opacity", "opacity_sigmoid"), ("l_d", "l_d_STAND_IN_SH")):
+                np.testing.assert_allclose(cam[mine].cpu().numpy(), z[f"{name}/cam{c}/{theirs}"], rtol=2e-5, atol=1e-6, err_msg=f"{fused} {c} {mine}")
 
 
-def test_parameter_gradients_match_dense_oracle(device):
+@pytest.mark.parametrize("fused", [True, False])
+def test_parameter_gradients_match_dense_oracle(fused, device):
     """d(loss)/d(mean, q, scale, opacity, colour) through projection + HIP Function (fp32) against the same projection
     followed by the dense autograd renderer in fp64 on the CPU."""
     name = CASES[0]
@@ -62,13 +68,15 @@ def test_parameter_gradients_match_dense_oracle(device):
     h, wd = int(w["wh"][0, 1]), int(w["wh"][0, 0])
     wimg = torch.randn(n_cam, 3, h, wd, generator=torch.Generator().manual_seed(4))
     model = make_model(w)
+    if not fused:
+        model.camera_inputs = lambda P, K, wh: gm.GS_model_with_param.camera_inputs(model, P, K, wh, fused=False)
     images = model(w["P"], w["K"], w["wh"], list(range(n_cam)))[0]
     (images * wimg.to(device)).sum().backward()
 
     wc = {k: v.cpu() for k, v in w.items()}
     leaves = {k: wc[k].clone().requires_grad_(True) for k in ("mean", "variance_q", "variance_scale", "opacity", "color")}
     cams, _, _ = gm.camera_inputs(leaves["mean"], leaves["variance_q"], leaves["variance_scale"], leaves["opacity"], leaves["color"],
-                                  wc["P"], wc["K"], wc["wh"], TILE_LOGIT)
+                                  wc["P"], wc["K"], wc["wh"], TILE_LOGIT, fused=False)
     dense = torch.stack([dense_render.render(c["startpoint"], c["endpoint"], c["mean"], c["variance_inverse"], c["opacity"], c["l_d"],
                                              wd, h, dtype=torch.float64) for c in cams])
     dense = dense[:, 1:, 1:, :].permute(0, 3, 1, 2)
@@ -80,6 +88,83 @@ def test_parameter_gradients_match_dense_oracle(device):
         scale = want.abs().max().item()
         assert scale > 0, k
         assert (got - want).abs().max().item() <= 2e-4 * scale, (k, (got - want).abs().max().item(), scale)
+
+
+def random_world(n, n_cam, width, height, seed, device, sigma=0.05):
+    from examples.train_cameras import ring_cameras
+
+    g = torch.Generator().manual_seed(seed)
+    P, K, wh = ring_cameras(n_cam, width, height, device=device)
+    w = {"mean": torch.randn(n, 3, generator=g) * torch.tensor([0.9, 0.6, 0.9]), "variance_q": torch.randn(n, 4, generator=g),
+         "variance_scale": torch.log(sigma * (0.4 + 1.2 * torch.rand(n, 3, generator=g))),
+         "opacity": torch.logit(0.02 + 0.96 * torch.rand(n, 1, generator=g)), "color": 0.5 * torch.randn(n, 9, 3, generator=g)}
+    w["mean"][: n // 20] *= 6  # some behind / beside the cameras
+    w = {k: v.to(device) for k, v in w.items()}
+    w.update(P=P, K=K, wh=wh)
+    return w
+
+
+@pytest.mark.parametrize("n,n_cam,width,height,sh_degree", [(20000, 3, 160, 120, 2), (5000, 2, 64, 48, 1), (300, 1, 40, 30, 0)])
+def test_fused_projection_equals_torch_formulation(n, n_cam, width, height, sh_degree, device):
+    """gcp_project_forward / _backward against the PyTorch formulation (itself pinned to the reference's forward):
+    same cull set and depth order, integers equal, floats and all five parameter gradients within fp32 round-off."""
+    w = random_world(n, n_cam, width, height, 7 + n, device)
+    names = ("mean", "variance_q", "variance_scale", "opacity", "color")
+    results = {}
+    for fused in (True, False):
+        leaves = {k: w[k].clone().requires_grad_(True) for k in names}
+        cams, grad_iter, _ = gm.camera_inputs(*(leaves[k] for k in names), w["P"], w["K"], w["wh"], TILE_LOGIT, L_max=sh_degree, fused=fused)
+        gen = torch.Generator().manual_seed(1)
+        loss = 0
+        for cam in cams:  # upstream gradients belong to Gaussians, not to rows: the row order may differ by near-ties in depth
+            for k in ("variance_inverse", "opacity", "l_d"):
+                loss = loss + (cam[k] * torch.randn((n, *cam[k].shape[1:]), generator=gen).to(device)[cam["index"]]).sum()
+        loss.backward()
+        results[fused] = (cams, grad_iter, {k: v.grad for k, v in leaves.items()})
+    (cf, gf, gradf), (ct, gt, gradt) = results[True], results[False]
+    assert torch.equal(gf, gt)
+    flips = 0
+    for c, (a, b) in enumerate(zip(cf, ct)):
+        # same cull set (up to values that sit within an ulp of a threshold) ...
+        sa, sb = set(a["index"].tolist()), set(b["index"].tolist())
+        flips += len(sa ^ sb)
+        # ... in depth order: depths that differ by an ulp between the formulations may swap neighbours
+        z = (torch.cat([w["mean"], torch.ones(n, 1, device=device)], 1) @ w["P"][c].T)[:, 2].double()
+        za = z[a["index"]]
+        assert bool((za[1:] - za[:-1] >= -1e-5 * za[1:].abs().clamp_min(1.0)).all())
+        common = torch.tensor(sorted(sa & sb), device=device)
+        ra = torch.full((n,), -1, device=device, dtype=torch.long)
+        rb = ra.clone()
+        ra[a["index"]] = torch.arange(a["index"].numel(), device=device)
+        rb[b["index"]] = torch.arange(b["index"].numel(), device=device)
+        for k in ("startpoint", "endpoint", "mean", "boxsize"):
+            assert a[k].dtype == b[k].dtype
+            flips += int((a[k][ra[common]] != b[k][rb[common]]).sum())
+        for k in ("variance_inverse", "opacity", "l_d"):
+            torch.testing.assert_close(a[k][ra[common]], b[k][rb[common]], rtol=2e-4, atol=1e-6)
+    # a float that lands within an ulp of an integer may truncate differently in the two formulations
+    assert flips <= max(2, n * n_cam // 5000), flips
+    for k in names:
+        scale = gradt[k].abs().max().item()
+        assert scale > 0, k
+        err = (gradf[k] - gradt[k]).abs().max().item()
+        assert err <= 5e-4 * scale, (k, err, scale)
+    if sh_degree < 2:  # unused coefficients get no gradient
+        assert float(gradf["color"][:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
+
+
+def test_fused_projection_argument_checks(device):
+    w = random_world(50, 1, 32, 24, 3, device)
+    args = [w[k] for k in ("mean", "variance_q", "variance_scale", "opacity", "color")]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gm.camera_inputs(*(a.cpu() for a in args), w["P"].cpu(), w["K"].cpu(), w["wh"].cpu(), TILE_LOGIT, fused=True)
+    with pytest.raises(ValueError):
+        gm.camera_inputs(*args, w["P"], w["K"], w["wh"], TILE_LOGIT, sh=lambda d, s, v: s[..., 0], fused=True)
+    with pytest.raises(RuntimeError):  # degree 3 is refused by the library
+        gm.camera_inputs(*args, w["P"], w["K"], w["wh"], TILE_LOGIT, L_max=3, fused=True)
+    empty = [a[:0] for a in args]
+    cams, grad_iter, _ = gm.camera_inputs(*empty, w["P"], w["K"], w["wh"], TILE_LOGIT, fused=True)
+    assert cams == [None] and grad_iter.numel() == 0
 
 
 def test_invisible_cameras_are_dropped(device):

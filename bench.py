@@ -124,6 +124,55 @@ def function_level(dev, workload):
     }
 
 
+def caller_level(dev, workload):
+    """Row f4 (outside the timed region, informational): one training step of the caller — camera projection,
+    Function, L1 loss, backward to the five parameter tensors — on 10^6 Gaussians and one 1920x1080 camera, with the
+    fused projection kernels and, once, with the reference's op-by-op PyTorch formulation of the projection
+    (gs_model.py:277-425) around the same Function."""
+    import time
+
+    import torch
+
+    from simplegaussiansplat_tk71_amd import gs_model as gm
+    from simplegaussiansplat_tk71_amd import synthetic
+
+    if workload != "cfg3":
+        return None
+    width, height, n = 1920, 1080, 1_000_000
+    P, K, wh = synthetic.ring_cameras(1, width, height, device=dev)
+    model = gm.GS_model_with_param(*synthetic.make_world(n, width, 2.0, seed=0, device=dev))
+    target = torch.rand(1, 3, height, width, device=dev)
+
+    def step():
+        images = model(P, K, wh, [0])[0]
+        (images - target).abs().mean().backward()
+        model._optimizer.zero_grad(set_to_none=True)
+
+    def timed(reps):
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    cams, _, _ = model.camera_inputs(P, K, wh)
+    pairs = int(cams[0]["boxsize"].sum())
+    fused_ms = timed(5)
+    model.camera_inputs = lambda P, K, wh: gm.GS_model_with_param.camera_inputs(model, P, K, wh, fused=False)
+    torch_ms = timed(1)
+    return {
+        "what": "GS_model_with_param: projection + Function + L1 loss, forward and backward, one 1920x1080 camera",
+        "gaussians": n,
+        "visible": int(cams[0]["boxsize"].numel()),
+        "pairs": pairs,
+        "step_ms": fused_ms,
+        "step_ms_reference_formulation_of_projection": torch_ms,
+        "pairs_per_s": pairs / (fused_ms * 1e-3),
+    }
+
+
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -318,6 +367,7 @@ def main():
         }
         if world == 1:
             out["function_level"] = function_level(dev, args.workload)
+            out["caller_level"] = caller_level(dev, args.workload)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(p, args.cpu_sample)
         print(json.dumps(out), flush=True)

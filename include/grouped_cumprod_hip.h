@@ -252,21 +252,28 @@ int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t
  * One camera of GS_model_with_param.forward up to the Function call (reference: gs_model.py:289-365, :404-425;
  * helpers uitility.py:231-287, :431-462): world->camera, pinhole projection, pixel covariance J W S W^T J^T + 1e-6 I,
  * 3-sigma box from its eigen-decomposition, its inverse, SH colour (degree <= 2, coefficients [n_basis][3] per
- * Gaussian), sigmoid opacity, the cull test and the clamped integer box.  All outputs are in the Gaussians' own
- * order (n_gauss rows); the caller sorts the kept ones by `depth` (stable) and gathers.
+ * Gaussian), sigmoid opacity, the cull test and the clamped integer box.
  *   cam_P float[12] = [R|t] row major, cam_K float[9] row major, both in device memory;
  *   box_clamp = the float the 3-sigma half extents are clamped to before truncation (gs_model.py:364-365).
- * gcp_project_backward ADDS, for the n_kept rows `index` (Gaussian ids, any order, each at most once), the
- * gradients of (mean, quaternion, log scale, opacity logit, SH coefficients) given those of (Sigma'^-1 [4],
- * opacity, l_d [3]) of the same rows; gradient arrays have n_gauss rows and are zeroed by the caller. */
+ * gcp_project_forward writes, in the Gaussians' own order: record float[n_gauss][16] (16-byte aligned; opaque, read
+ * back by gcp_project_gather), sort_key int32 (bit pattern of the positive camera depth, 0x7fffffff for culled
+ * Gaussians: a stable ascending sort of the keys IS the depth order of gs_model.py:356 with the kept ones first),
+ * keep uint8 (the cull mask of gs_model.py:405-407) and row_of = -1.
+ * gcp_project_gather: for the first n_kept entries of the sorted permutation `perm`, the Function's arguments in
+ * depth order (boxes, pixel means, boxsize = gs_model.py:425, Sigma'^-1 [4], opacity, l_d [3], index = Gaussian id)
+ * and row_of[index[r]] = r.
+ * gcp_project_backward: gradients of (mean, quaternion, log scale, opacity logit, SH coefficients), n_gauss rows
+ * each, all rows written (zeros where row_of < 0), from those of (Sigma'^-1, opacity, l_d) in list order. */
 int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
                         const float* sh_coeff, const float* cam_P, const float* cam_K, int64_t n_gauss, int32_t sh_degree,
-                        int32_t n_basis, int32_t width, int32_t height, float box_clamp, float* depth, uint8_t* keep,
-                        int32_t* start_xy, int32_t* end_xy, int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha,
-                        float* l_d, void* stream);
+                        int32_t n_basis, int32_t width, int32_t height, float box_clamp, float* record, int32_t* sort_key,
+                        uint8_t* keep, int32_t* row_of, void* stream);
+int gcp_project_gather(const float* record, const int32_t* perm, int64_t n_kept, int32_t* start_xy, int32_t* end_xy,
+                       int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha, float* l_d, int64_t* index,
+                       int32_t* row_of, void* stream);
 int gcp_project_backward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
-                         const float* sh_coeff, const float* cam_P, const float* cam_K, int32_t sh_degree, int32_t n_basis,
-                         const int64_t* index, int64_t n_kept, const float* grad_vinv, const float* grad_alpha,
+                         const float* sh_coeff, const float* cam_P, const float* cam_K, int64_t n_gauss, int32_t sh_degree,
+                         int32_t n_basis, const int32_t* row_of, const float* grad_vinv, const float* grad_alpha,
                          const float* grad_l_d, float* grad_mean, float* grad_quat, float* grad_log_scale,
                          float* grad_opacity_logit, float* grad_sh_coeff, void* stream);
 

@@ -64,8 +64,9 @@ SIGNATURES = {
     "gcp_expand_rects": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p]),
     "gcp_pixel_lists_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5),
     "gcp_pixel_lists_fill": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 8),
-    "gcp_project_forward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32, _i32, _i32, ctypes.c_float] + [_c_void_p] * 10),
-    "gcp_project_backward": (ctypes.c_int, [_c_void_p] * 7 + [_i32, _i32, _c_void_p, _i64] + [_c_void_p] * 9),
+    "gcp_project_forward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32, _i32, _i32, ctypes.c_float] + [_c_void_p] * 5),
+    "gcp_project_gather": (ctypes.c_int, [_c_void_p, _c_void_p, _i64] + [_c_void_p] * 10),
+    "gcp_project_backward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32] + [_c_void_p] * 10),
 }
 
 ABI_VERSION = 1

@@ -6,7 +6,9 @@
 // k_project_fwd writes, in the Gaussians' own order, everything the Function needs of it for one camera;
 // k_project_bwd recomputes the chain in registers and turns (dL/dSigma'^-1, dL/dopacity, dL/dl_d) into the
 // gradients of (mean, quaternion, log-scale, opacity logit, SH coefficients).  HBM bound: 152 B in, 77 B out per
-// Gaussian forward; no LDS, no cross-lane traffic.
+// Gaussian forward; no LDS, no cross-lane traffic.  Depth order: the forward also emits a 31-bit sort key per
+// Gaussian (bits of the positive depth; culled last) for gcp_sort_pairs_u32, and k_project_gather unpacks the
+// kept records in that order.
 //
 // The arithmetic follows the reference's order of operations (matrix products accumulated left to right, k
 // ascending, no FMA contraction: the library is built with -ffp-contract=off) so that the integer boxes that come
@@ -145,13 +147,14 @@ __device__ __forceinline__ void box_halfsize(float a, float b, float c, float& h
 
 __device__ __forceinline__ int trunc_i32(float v) { return (int)v; }
 
+// Per Gaussian, one 64-byte record (what the gather reads back in one piece), the sort key of its depth and the cull flag.
+//   record words: 0-3 box x0 y0 x1 y1 | 4-5 pixel mean | 6-9 Sigma'^-1 | 10 opacity | 11-13 colour | 14-15 unused
+
 __global__ __launch_bounds__(kThreads) void k_project_fwd(
     const float* __restrict__ mean, const float* __restrict__ q, const float* __restrict__ log_scale,
     const float* __restrict__ opacity, const float* __restrict__ color, const float* __restrict__ cam_P,
     const float* __restrict__ cam_K, i64 n, int sh_degree, int n_basis, int width, int height, float box_clamp,
-    float* __restrict__ depth, uint8_t* __restrict__ keep, int* __restrict__ start_xy, int* __restrict__ end_xy,
-    int* __restrict__ mean_xy, i64* __restrict__ boxsize, float* __restrict__ vinv, float* __restrict__ alpha,
-    float* __restrict__ l_d) {
+    float4* __restrict__ record, int* __restrict__ sort_key, uint8_t* __restrict__ keep, int* __restrict__ row_of) {
   const Camera cam = load_camera(cam_P, cam_K);
   for (i64 i = (i64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (i64)gridDim.x * kThreads) {
     Projected p;
@@ -159,22 +162,19 @@ __global__ __launch_bounds__(kThreads) void k_project_fwd(
     float hx, hy;
     box_halfsize(p.a, p.c, p.d, hx, hy);
     const float ilim = 2147483647.f / 1000.f;
-    const int mx = trunc_i32(clampf(p.px, -ilim - 0.001f, ilim)), my = trunc_i32(clampf(p.py, -ilim - 0.001f, ilim));
+    const int mx = trunc_i32(clampf(p.px, -ilim, ilim)), my = trunc_i32(clampf(p.py, -ilim, ilim));
     const int bw = trunc_i32(fminf(hx, box_clamp)), bh = trunc_i32(fminf(hy, box_clamp));
     const bool k = p.t[2] > 0.f && bw != 0 && mx - bw < width && mx + bw > 0 && my - bh < height && my + bh > 0;
     const int x0 = min(max(mx - bw, 0), width), y0 = min(max(my - bh, 0), height);
     const int x1 = min(max(mx + bw, 0), width), y1 = min(max(my + bh, 0), height);
-    depth[i] = p.t[2];
     keep[i] = k ? 1 : 0;
-    start_xy[2 * i] = x0, start_xy[2 * i + 1] = y0;
-    end_xy[2 * i] = x1, end_xy[2 * i + 1] = y1;
-    mean_xy[2 * i] = mx, mean_xy[2 * i + 1] = my;
-    boxsize[i] = (i64)(x1 - x0 + 1) * (i64)(y1 - y0 + 1);
-    vinv[4 * i] = p.d / p.det, vinv[4 * i + 1] = -p.b / p.det, vinv[4 * i + 2] = -p.c / p.det, vinv[4 * i + 3] = p.a / p.det;
-    alpha[i] = 1.f / (1.f + expf(-opacity[i]));
+    row_of[i] = -1;
+    // kept depths are positive floats: their bit patterns sort like the values; culled Gaussians sort last
+    sort_key[i] = k ? __float_as_int(p.t[2]) : 0x7fffffff;
     // real spherical harmonics, degree <= 2 (the build's eval_sh; the reference's sh_utility is absent)
     const float* sh = color + (i64)i * n_basis * 3;
     const float x = p.view[0], y = p.view[1], z = p.view[2];
+    float l[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       float v = kShC0 * sh[ch];
@@ -187,29 +187,68 @@ __global__ __launch_bounds__(kThreads) void k_project_fwd(
               kShC2[4] * (xx - yy) * sh[24 + ch];
         }
       }
-      l_d[3 * i + ch] = v;
+      l[ch] = v;
     }
+    const float alpha = 1.f / (1.f + expf(-opacity[i]));
+    float4* rec = record + 4 * i;
+    rec[0] = make_float4(__int_as_float(x0), __int_as_float(y0), __int_as_float(x1), __int_as_float(y1));
+    rec[1] = make_float4(__int_as_float(mx), __int_as_float(my), p.d / p.det, -p.b / p.det);
+    rec[2] = make_float4(-p.c / p.det, p.a / p.det, alpha, l[0]);
+    rec[3] = make_float4(l[1], l[2], 0.f, 0.f);
   }
 }
 
-// One thread per kept Gaussian (row r of the depth-ordered list, Gaussian index[r]).  Gradients are ADDED to the
-// per-Gaussian arrays: a Gaussian occurs at most once per camera, cameras are launched one after the other.
+// Row r of the depth-ordered list is Gaussian perm[r]: unpack its record into the Function's argument arrays.
+__global__ __launch_bounds__(kThreads) void k_project_gather(
+    const float4* __restrict__ record, const int* __restrict__ perm, i64 m, int* __restrict__ start_xy,
+    int* __restrict__ end_xy, int* __restrict__ mean_xy, i64* __restrict__ boxsize, float* __restrict__ vinv,
+    float* __restrict__ alpha, float* __restrict__ l_d, i64* __restrict__ index, int* __restrict__ row_of) {
+  for (i64 r = (i64)blockIdx.x * kThreads + threadIdx.x; r < m; r += (i64)gridDim.x * kThreads) {
+    const int i = perm[r];
+    const float4* rec = record + 4 * (i64)i;
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+    const int x0 = __float_as_int(a.x), y0 = __float_as_int(a.y), x1 = __float_as_int(a.z), y1 = __float_as_int(a.w);
+    reinterpret_cast<int2*>(start_xy)[r] = make_int2(x0, y0);
+    reinterpret_cast<int2*>(end_xy)[r] = make_int2(x1, y1);
+    reinterpret_cast<int2*>(mean_xy)[r] = make_int2(__float_as_int(b.x), __float_as_int(b.y));
+    boxsize[r] = (i64)(x1 - x0 + 1) * (i64)(y1 - y0 + 1);
+    reinterpret_cast<float4*>(vinv)[r] = make_float4(b.z, b.w, c.x, c.y);
+    alpha[r] = c.z;
+    l_d[3 * r] = c.w, l_d[3 * r + 1] = d.x, l_d[3 * r + 2] = d.y;
+    index[r] = i;
+    row_of[i] = (int)r;
+  }
+}
+
+// One thread per Gaussian, in the Gaussians' own order (coalesced parameter reads and gradient writes); the only
+// scattered reads are the 8 upstream gradient words of its row `row_of[i]` in the depth-ordered list.  Culled
+// Gaussians (row -1) get zeros: every gradient row is written, nothing needs clearing first.
 __global__ __launch_bounds__(kThreads) void k_project_bwd(
     const float* __restrict__ mean, const float* __restrict__ q, const float* __restrict__ log_scale,
     const float* __restrict__ opacity, const float* __restrict__ color, const float* __restrict__ cam_P,
-    const float* __restrict__ cam_K, int sh_degree, int n_basis, const i64* __restrict__ index, i64 m,
+    const float* __restrict__ cam_K, i64 n, int sh_degree, int n_basis, const int* __restrict__ row_of,
     const float* __restrict__ g_vinv, const float* __restrict__ g_alpha, const float* __restrict__ g_ld,
     float* __restrict__ grad_mean, float* __restrict__ grad_q, float* __restrict__ grad_log_scale,
     float* __restrict__ grad_opacity, float* __restrict__ grad_color) {
   const Camera cam = load_camera(cam_P, cam_K);
-  for (i64 r = (i64)blockIdx.x * kThreads + threadIdx.x; r < m; r += (i64)gridDim.x * kThreads) {
-    const i64 i = index[r];
+  for (i64 i = (i64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (i64)gridDim.x * kThreads) {
+    const i64 r = row_of[i];
+    float* gsh = grad_color + (i64)i * n_basis * 3;
+    if (r < 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) grad_mean[3 * i + k] = 0.f, grad_log_scale[3 * i + k] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) grad_q[4 * i + k] = 0.f;
+      grad_opacity[i] = 0.f;
+      for (int k = 0; k < 3 * n_basis; ++k) gsh[k] = 0.f;
+      continue;
+    }
     Projected p;
     project_one(cam, mean, q, log_scale, i, p);
 
     // opacity = sigmoid(o)
     const float al = 1.f / (1.f + expf(-opacity[i]));
-    grad_opacity[i] += g_alpha[r] * al * (1.f - al);
+    grad_opacity[i] = g_alpha[r] * al * (1.f - al);
 
     // colour: l_d[ch] = sum_k B_k(view) sh[k][ch]
     const float x = p.view[0], y = p.view[1], z = p.view[2];
@@ -217,12 +256,14 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
                    kShC2[2] * (2.f * z * z - x * x - y * y), kShC2[3] * x * z, kShC2[4] * (x * x - y * y)};
     const int nb = (sh_degree + 1) * (sh_degree + 1);
     const float* sh = color + (i64)i * n_basis * 3;
-    float* gsh = grad_color + (i64)i * n_basis * 3;
     float gv[3] = {0.f, 0.f, 0.f};  // dL/dview
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float g = g_ld[3 * r + ch];
-      for (int k = 0; k < nb; ++k) gsh[3 * k + ch] += g * Bk[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (k < n_basis) gsh[3 * k + ch] = k < nb ? g * Bk[k] : 0.f;
+      for (int k = 9; k < n_basis; ++k) gsh[3 * k + ch] = 0.f;
       if (sh_degree > 0) {
         gv[0] += g * (-kShC1 * sh[9 + ch]);
         gv[1] += g * (-kShC1 * sh[3 + ch]);
@@ -286,7 +327,7 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
     }
     // t = W m + t0  ->  dL/dm = W^T dL/dt
 #pragma unroll
-    for (int k = 0; k < 3; ++k) grad_mean[3 * i + k] += (cam.P[k] * gt[0] + cam.P[4 + k] * gt[1]) + cam.P[8 + k] * gt[2];
+    for (int k = 0; k < 3; ++k) grad_mean[3 * i + k] = (cam.P[k] * gt[0] + cam.P[4 + k] * gt[1]) + cam.P[8 + k] * gt[2];
 
     // Sc = W S W^T  ->  E = dL/dS = W^T gSc W
     float E[9];
@@ -318,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc += R[3 * a + k] * E[3 * a + b] * R[3 * b + k];
-      grad_log_scale[3 * i + k] += 2.f * (p.s[k] * p.s[k]) * acc;
+      grad_log_scale[3 * i + k] = 2.f * (p.s[k] * p.s[k]) * acc;
     }
     // R(qn), qn = q / |q|
     {
@@ -331,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
       const float dot = g[0] * qx + g[1] * qy + g[2] * qz + g[3] * qw;
       const bool clamped = !(p.qlen > 1e-8f);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) grad_q[4 * i + k] += clamped ? g[k] / p.qlen : (g[k] - p.qn[k] * dot) / p.qlen;
+      for (int k = 0; k < 4; ++k) grad_q[4 * i + k] = clamped ? g[k] / p.qlen : (g[k] - p.qn[k] * dot) / p.qlen;
     }
   }
 }
@@ -344,35 +385,49 @@ extern "C" {
 
 int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
                         const float* sh_coeff, const float* cam_P, const float* cam_K, int64_t n_gauss, int32_t sh_degree,
-                        int32_t n_basis, int32_t width, int32_t height, float box_clamp, float* depth, uint8_t* keep,
-                        int32_t* start_xy, int32_t* end_xy, int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha,
-                        float* l_d, void* stream) {
-  if (n_gauss < 0 || sh_degree < 0 || sh_degree > 2 || n_basis < (sh_degree + 1) * (sh_degree + 1) || width < 0 || height < 0)
+                        int32_t n_basis, int32_t width, int32_t height, float box_clamp, float* record, int32_t* sort_key,
+                        uint8_t* keep, int32_t* row_of, void* stream) {
+  if (n_gauss < 0 || n_gauss > 0x7fffffff || sh_degree < 0 || sh_degree > 2 || n_basis < (sh_degree + 1) * (sh_degree + 1) ||
+      width < 0 || height < 0)
     return GCP_ERR_INVALID_ARGUMENT;
   if (n_gauss == 0) return GCP_OK;
-  if (!mean || !quat_xyzw || !log_scale || !opacity_logit || !sh_coeff || !cam_P || !cam_K || !depth || !keep || !start_xy ||
-      !end_xy || !mean_xy || !boxsize || !vinv || !alpha || !l_d)
+  if (!mean || !quat_xyzw || !log_scale || !opacity_logit || !sh_coeff || !cam_P || !cam_K || !record || !sort_key || !keep ||
+      !row_of || ((uintptr_t)record & 15))
     return GCP_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_project_fwd, dim3(grid_for(n_gauss)), dim3(kThreads), 0, (hipStream_t)stream, mean, quat_xyzw, log_scale,
                      opacity_logit, sh_coeff, cam_P, cam_K, (i64)n_gauss, (int)sh_degree, (int)n_basis, (int)width, (int)height,
-                     box_clamp, depth, keep, start_xy, end_xy, mean_xy, (i64*)boxsize, vinv, alpha, l_d);
+                     box_clamp, (float4*)record, sort_key, keep, row_of);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_project_gather(const float* record, const int32_t* perm, int64_t n_kept, int32_t* start_xy, int32_t* end_xy,
+                       int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha, float* l_d, int64_t* index,
+                       int32_t* row_of, void* stream) {
+  if (n_kept < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_kept == 0) return GCP_OK;
+  if (!record || !perm || !start_xy || !end_xy || !mean_xy || !boxsize || !vinv || !alpha || !l_d || !index || !row_of ||
+      (((uintptr_t)record | (uintptr_t)vinv) & 15) || (((uintptr_t)start_xy | (uintptr_t)end_xy | (uintptr_t)mean_xy) & 7))
+    return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_project_gather, dim3(grid_for(n_kept)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)record, perm,
+                     (i64)n_kept, start_xy, end_xy, mean_xy, (i64*)boxsize, vinv, alpha, l_d, (i64*)index, row_of);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 
 int gcp_project_backward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
-                         const float* sh_coeff, const float* cam_P, const float* cam_K, int32_t sh_degree, int32_t n_basis,
-                         const int64_t* index, int64_t n_kept, const float* grad_vinv, const float* grad_alpha,
+                         const float* sh_coeff, const float* cam_P, const float* cam_K, int64_t n_gauss, int32_t sh_degree,
+                         int32_t n_basis, const int32_t* row_of, const float* grad_vinv, const float* grad_alpha,
                          const float* grad_l_d, float* grad_mean, float* grad_quat, float* grad_log_scale,
                          float* grad_opacity_logit, float* grad_sh_coeff, void* stream) {
-  if (n_kept < 0 || sh_degree < 0 || sh_degree > 2 || n_basis < (sh_degree + 1) * (sh_degree + 1)) return GCP_ERR_INVALID_ARGUMENT;
-  if (n_kept == 0) return GCP_OK;
-  if (!mean || !quat_xyzw || !log_scale || !opacity_logit || !sh_coeff || !cam_P || !cam_K || !index || !grad_vinv ||
-      !grad_alpha || !grad_l_d || !grad_mean || !grad_quat || !grad_log_scale || !grad_opacity_logit || !grad_sh_coeff)
-    return GCP_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_project_bwd, dim3(grid_for(n_kept)), dim3(kThreads), 0, (hipStream_t)stream, mean, quat_xyzw, log_scale,
-                     opacity_logit, sh_coeff, cam_P, cam_K, (int)sh_degree, (int)n_basis, (const i64*)index, (i64)n_kept,
-                     grad_vinv, grad_alpha, grad_l_d, grad_mean, grad_quat, grad_log_scale, grad_opacity_logit, grad_sh_coeff);
+  if (n_gauss < 0 || sh_degree < 0 || sh_degree > 2 || n_basis < (sh_degree + 1) * (sh_degree + 1)) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0) return GCP_OK;
+  if (!mean || !quat_xyzw || !log_scale || !opacity_logit || !sh_coeff || !cam_P || !cam_K || !row_of || !grad_mean ||
+      !grad_quat || !grad_log_scale || !grad_opacity_logit || !grad_sh_coeff)
+    return GCP_ERR_INVALID_ARGUMENT;  // the three upstream arrays may be NULL when no Gaussian was kept
+  hipLaunchKernelGGL(k_project_bwd, dim3(grid_for(n_gauss)), dim3(kThreads), 0, (hipStream_t)stream, mean, quat_xyzw, log_scale,
+                     opacity_logit, sh_coeff, cam_P, cam_K, (i64)n_gauss, (int)sh_degree, (int)n_basis, row_of, grad_vinv, grad_alpha,
+                     grad_l_d, grad_mean, grad_quat, grad_log_scale, grad_opacity_logit, grad_sh_coeff);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

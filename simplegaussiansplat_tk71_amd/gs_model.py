@@ -28,6 +28,7 @@ import math
 import torch
 
 from . import _lib
+from . import raster as _raster
 from .cuda_kernel import custom_autograd_grouped_cumprod
 
 __all__ = [
@@ -143,8 +144,8 @@ def _box_clamp(wh, tile_max_width, dev):
 
 
 class _ProjectCamera(torch.autograd.Function):
-    """One camera of `camera_inputs` on the HIP library: gcp_project_forward, a stable sort of the kept Gaussians by
-    depth, gathers; backward = gcp_project_backward (csrc/gcp_project.hip)."""
+    """One camera of `camera_inputs` on the HIP library (csrc/gcp_project.hip): gcp_project_forward, the library's
+    stable radix sort on the depth keys, gcp_project_gather; backward = gcp_project_backward."""
 
     @staticmethod
     def forward(ctx, mean, variance_q, variance_scale, opacity, color, cam_P, cam_K, width, height, box_clamp, L_max):
@@ -155,36 +156,42 @@ class _ProjectCamera(torch.autograd.Function):
                 raise RuntimeError("projection expects float32 tensors on one device")
         if not mean.is_cuda:
             raise RuntimeError("the fused projection is a HIP kernel: tensors must live on the GPU (no CPU path)")
+        lib = _lib.load()
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
         i32 = lambda *shape: torch.empty(shape, dtype=torch.int32, device=dev)  # noqa: E731
-        depth, keep = f32(n), torch.empty(n, dtype=torch.uint8, device=dev)
-        start, end, mean_xy, boxsize = i32(n, 2), i32(n, 2), i32(n, 2), torch.empty(n, dtype=torch.int64, device=dev)
-        vinv, alpha, l_d = f32(n, 2, 2), f32(n, 1), f32(n, 3)
+        record, sort_key, row_of = f32(n, 16), i32(n), i32(n)
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(_lib.load().gcp_project_forward(
-                *(t.data_ptr() for t in args), n, L_max, color.shape[1], width, height, box_clamp, depth.data_ptr(),
-                keep.data_ptr(), start.data_ptr(), end.data_ptr(), mean_xy.data_ptr(), boxsize.data_ptr(), vinv.data_ptr(),
-                alpha.data_ptr(), l_d.data_ptr(), stream), "gcp_project_forward")
+            _lib.check(lib.gcp_project_forward(*(t.data_ptr() for t in args), n, L_max, color.shape[1], width, height, box_clamp,
+                                               record.data_ptr(), sort_key.data_ptr(), keep.data_ptr(), row_of.data_ptr(), stream),
+                       "gcp_project_forward")
+            m = int(keep.sum()) if n else 0  # the one device->host read: sizes of the outputs
+            # culled Gaussians carry the largest key: the first m entries of the stable permutation are the kept ones in
+            # depth order, ties in the Gaussians' own order
+            perm = _raster.stable_sort_keys(sort_key, key_bits=31)[1] if n else sort_key
+            start, end, mean_xy, boxsize = i32(m, 2), i32(m, 2), i32(m, 2), torch.empty(m, dtype=torch.int64, device=dev)
+            vinv, alpha, l_d, index = f32(m, 2, 2), f32(m, 1), f32(m, 3), torch.empty(m, dtype=torch.int64, device=dev)
+            _lib.check(lib.gcp_project_gather(record.data_ptr(), perm.data_ptr(), m, start.data_ptr(), end.data_ptr(),
+                                              mean_xy.data_ptr(), boxsize.data_ptr(), vinv.data_ptr(), alpha.data_ptr(),
+                                              l_d.data_ptr(), index.data_ptr(), row_of.data_ptr(), stream), "gcp_project_gather")
         keep = keep.view(torch.bool)
-        kept = keep.nonzero().squeeze(1)
-        index = kept[torch.sort(depth[kept], stable=True).indices]  # depth order; ties keep the Gaussians' order
-        ctx.save_for_backward(*args, index)
+        ctx.save_for_backward(*args, row_of)
         ctx.L_max = L_max
-        out = (vinv[index], alpha[index], l_d[index], start[index], end[index], mean_xy[index], boxsize[index], index, keep)
+        out = (vinv, alpha, l_d, start, end, mean_xy, boxsize, index, keep)
         ctx.mark_non_differentiable(*out[3:])
         return out
 
     @staticmethod
     def backward(ctx, g_vinv, g_alpha, g_ld, *_):
-        *args, index = ctx.saved_tensors
+        *args, row_of = ctx.saved_tensors
         mean, variance_q, variance_scale, opacity, color = args[:5]
-        grads = [torch.zeros_like(t) for t in (mean, variance_q, variance_scale, opacity, color)]
+        grads = [torch.empty_like(t) for t in (mean, variance_q, variance_scale, opacity, color)]  # every row is written
         g = [t.contiguous().float() for t in (g_vinv, g_alpha, g_ld)]
         with torch.cuda.device(mean.device):
             stream = torch.cuda.current_stream(mean.device).cuda_stream
             _lib.check(_lib.load().gcp_project_backward(
-                *(t.data_ptr() for t in args), ctx.L_max, color.shape[1], index.data_ptr(), index.numel(),
+                *(t.data_ptr() for t in args), mean.shape[0], ctx.L_max, color.shape[1], row_of.data_ptr(),
                 *(t.data_ptr() for t in g), *(t.data_ptr() for t in grads), stream), "gcp_project_backward")
         return (*grads, None, None, None, None, None, None)
 

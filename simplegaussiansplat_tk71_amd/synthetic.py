@@ -127,3 +127,35 @@ def make_scene(n_gauss, width, height, mean_depth, seed=0, device="cpu"):
 def make_scene_config(name, seed=0, device="cpu"):
     c = CONFIGS[name]
     return make_scene(c["gaussians"], c["width"] - 1, c["height"] - 1, c["mean_depth"], seed, device)
+
+
+def ring_cameras(n_cam, width, height, radius=3.2, device="cpu"):
+    """World->camera [R|t] (n,3,4), intrinsics (n,3,3) and (n,2) sizes of cameras on a ring looking at the origin
+    (COLMAP convention: x right, y down, z forward) — the camera side of the caller tests and benches (row f4)."""
+    import math
+
+    P, K = [], []
+    for c in range(n_cam):
+        ang = 2 * math.pi * c / n_cam + 0.3
+        eye = torch.tensor([radius * math.cos(ang), 0.5 * math.sin(2 * ang), radius * math.sin(ang)])
+        fwd = -eye / eye.norm()
+        right = torch.linalg.cross(torch.tensor([0.0, -1.0, 0.0]), fwd)
+        right = right / right.norm()
+        R = torch.stack([right, torch.linalg.cross(fwd, right), fwd])
+        P.append(torch.cat([R, (-R @ eye)[:, None]], dim=1))
+        K.append(torch.tensor([[0.9 * width, 0, width / 2], [0, 0.9 * width, height / 2], [0, 0, 1.0]]))
+    wh = torch.tensor([[width, height]] * n_cam, dtype=torch.float32)
+    return torch.stack(P).to(device), torch.stack(K).to(device), wh.to(device)
+
+
+def make_world(n_gauss, width, sigma_px=2.0, seed=0, device="cpu", radius=3.2):
+    """3-D Gaussians for `ring_cameras`: a blob around the origin whose members project to about `sigma_px` pixels
+    (cfg3-like at 10^6 Gaussians, 1920x1080, sigma_px = 2: ~0.9e6 visible, ~1.6e8 splat-pixel pairs per camera).
+    Returns the parameter tensors of gs_model.GS_model_with_param: mean, variance_q, variance_scale, opacity (logit)."""
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.randn(n_gauss, 3, generator=g) * torch.tensor([0.9, 0.5, 0.6])
+    sigma_world = sigma_px * radius / (0.9 * width)
+    scale = torch.log(sigma_world * (0.6 + 0.8 * torch.rand(n_gauss, 3, generator=g)))
+    q = torch.randn(n_gauss, 4, generator=g)
+    op = torch.logit(0.05 + 0.9 * torch.rand(n_gauss, 1, generator=g))
+    return [t.to(device) for t in (mean, q, scale, op)]

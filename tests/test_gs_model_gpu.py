@@ -91,7 +91,7 @@ def test_parameter_gradients_match_dense_oracle(fused, device):
 
 
 def random_world(n, n_cam, width, height, seed, device, sigma=0.05):
-    from examples.train_cameras import ring_cameras
+    from simplegaussiansplat_tk71_amd.synthetic import ring_cameras
 
     g = torch.Generator().manual_seed(seed)
     P, K, wh = ring_cameras(n_cam, width, height, device=device)

@@ -10,8 +10,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from examples.train_cameras import ring_cameras  # noqa: E402
 from simplegaussiansplat_tk71_amd import gs_model as gm  # noqa: E402
+from simplegaussiansplat_tk71_amd.synthetic import make_world, ring_cameras  # noqa: E402
 
 
 def timed(fn, reps=5):
@@ -33,16 +33,10 @@ def main():
     ap.add_argument("--sigma-px", type=float, default=2.0)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    g = torch.Generator(device=dev).manual_seed(0)
     n = a.gaussians
     P, K, wh = ring_cameras(max(a.cameras, 1), a.width, a.height, device=dev)
     P, K, wh = P[:a.cameras], K[:a.cameras], wh[:a.cameras]
-    mean = torch.randn(n, 3, device=dev, generator=g) * torch.tensor([0.9, 0.5, 0.6], device=dev)
-    sigma_world = a.sigma_px * 3.2 / (0.9 * a.width)
-    scale = torch.log(sigma_world * (0.6 + 0.8 * torch.rand(n, 3, device=dev, generator=g)))
-    q = torch.randn(n, 4, device=dev, generator=g)
-    op = torch.logit(0.05 + 0.9 * torch.rand(n, 1, device=dev, generator=g))
-    model = gm.GS_model_with_param(mean, q, scale, op)
+    model = gm.GS_model_with_param(*make_world(n, a.width, a.sigma_px, seed=0, device=dev))
     names = list(range(a.cameras))
 
     t_proj, (cams, _, _) = timed(lambda: model.camera_inputs(P, K, wh))

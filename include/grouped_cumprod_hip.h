@@ -277,6 +277,24 @@ int gcp_project_backward(const float* mean, const float* quat_xyzw, const float*
                          const float* grad_l_d, float* grad_mean, float* grad_quat, float* grad_log_scale,
                          float* grad_opacity_logit, float* grad_sh_coeff, void* stream);
 
+/* ---- the caller's training loss, fused ---------------------------------------------------
+ * (1 - lambda) * mean|a - b| + lambda * (1 - mean SSIM(a, b)) of gs_control.py:180-182 (kornia.metrics.ssim with an
+ * 11-tap Gaussian window and reflect padding), over `planes` = batch * channels planes of height x width floats.
+ *   window11_host: the 11 normalised window weights, HOST memory (passed to the kernel by value); c1, c2 = (0.01 L)^2,
+ *   (0.03 L)^2.
+ * gcp_ssim_l1_forward writes partial[2 * b] = sum of the SSIM map and partial[2 * b + 1] = sum of |a - b| over block
+ * b of gcp_ssim_blocks() (no atomics: the caller adds them, in any fixed order, for a reproducible loss) and, when
+ * the three map pointers are non-NULL, dSSIM/dmu1, dSSIM/dE[a^2], dSSIM/dE[ab] per pixel for the backward.
+ * gcp_ssim_l1_backward: grad_img1 = scales[0] * dSum(SSIM)/da + scales[1] * sign(a - b), scales in DEVICE memory
+ * (so that an upstream gradient needs no host read); the adjoint of the reflect-padded blur is exact. */
+int64_t gcp_ssim_blocks(int64_t planes, int32_t height, int32_t width);
+int gcp_ssim_l1_forward(const float* img1, const float* img2, int64_t planes, int32_t height, int32_t width,
+                        const float* window11_host, float c1, float c2, float* dm_dmu1, float* dm_de11, float* dm_de12,
+                        float* partial, void* stream);
+int gcp_ssim_l1_backward(const float* img1, const float* img2, const float* dm_dmu1, const float* dm_de11, const float* dm_de12,
+                         int64_t planes, int32_t height, int32_t width, const float* window11_host, const float* scales,
+                         float* grad_img1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

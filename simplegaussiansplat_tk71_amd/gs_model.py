@@ -469,7 +469,69 @@ def ssim(img1, img2, window_size=11, max_val=1.0, sigma=1.5):
     return ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2) + 1e-12)
 
 
-def splat_loss(images, targets, lamda=0.2):
-    """(1 - lambda) L1 + lambda (1 - mean SSIM) (reference: gs_control.py:180-182)."""
+_WINDOW_CACHE = {}
+
+
+def _host_window(window_size, sigma):
+    """The normalised window as a ctypes float array (host memory, handed to the loss kernels by value)."""
+    import ctypes
+
+    key = (window_size, sigma)
+    if key not in _WINDOW_CACHE:
+        w = _gaussian_window(window_size, sigma, "cpu", torch.float32)
+        _WINDOW_CACHE[key] = (ctypes.c_float * window_size)(*w.tolist())
+    return _WINDOW_CACHE[key]
+
+
+class _SplatLoss(torch.autograd.Function):
+    """(1 - lambda) L1 + lambda (1 - mean SSIM) in one HIP kernel per direction (csrc/gcp_loss.hip); differentiable in
+    the first image only (the second is the target photograph)."""
+
+    @staticmethod
+    def forward(ctx, images, targets, lamda, max_val):
+        if not images.is_cuda:
+            raise RuntimeError("the fused loss is a HIP kernel: tensors must live on the GPU (no CPU path)")
+        if images.shape != targets.shape or images.dim() != 4:
+            raise RuntimeError("splat_loss expects two (B, C, H, W) tensors of one shape")
+        a, b = images.detach().contiguous().float(), targets.detach().contiguous().float()
+        bsz, ch, h, w = a.shape
+        lib = _lib.load()
+        win = _host_window(11, 1.5)
+        need_grad = images.requires_grad
+        maps = [torch.empty_like(a) for _ in range(3)] if need_grad else [None] * 3
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            partial = torch.empty(lib.gcp_ssim_blocks(bsz * ch, h, w), 2, dtype=torch.float32, device=a.device)
+            _lib.check(lib.gcp_ssim_l1_forward(a.data_ptr(), b.data_ptr(), bsz * ch, h, w, win, (0.01 * max_val) ** 2,
+                                               (0.03 * max_val) ** 2, *(m.data_ptr() if need_grad else None for m in maps),
+                                               partial.data_ptr(), stream), "gcp_ssim_l1_forward")
+        sums = partial.double().sum(dim=0) / a.numel()  # [mean SSIM, mean |a - b|]
+        ctx.save_for_backward(a, b, *(maps if need_grad else []))
+        ctx.lamda, ctx.dtype = lamda, images.dtype
+        return ((1 - lamda) * sums[1] + lamda * (1 - sums[0])).to(images.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a, b, m1, m2, m3 = ctx.saved_tensors
+        n = a.numel()
+        scales = (grad_out.reshape(1).float() * torch.tensor([-ctx.lamda / n, (1 - ctx.lamda) / n], device=a.device)).contiguous()
+        grad = torch.empty_like(a)
+        bsz, ch, h, w = a.shape
+        with torch.cuda.device(a.device):
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            _lib.check(_lib.load().gcp_ssim_l1_backward(a.data_ptr(), b.data_ptr(), m1.data_ptr(), m2.data_ptr(), m3.data_ptr(), bsz * ch,
+                                                        h, w, _host_window(11, 1.5), scales.data_ptr(), grad.data_ptr(), stream),
+                       "gcp_ssim_l1_backward")
+        return grad.to(ctx.dtype), None, None, None
+
+
+def splat_loss(images, targets, lamda=0.2, fused=None):
+    """(1 - lambda) L1 + lambda (1 - mean SSIM) (reference: gs_control.py:180-182).  On the GPU (`fused`, the default
+    there) both terms and their gradient are one HIP kernel per direction; `fused=False` is the PyTorch formulation
+    the kernel is tested against."""
+    if fused is None:
+        fused = images.is_cuda
+    if fused:
+        return _SplatLoss.apply(images, targets, float(lamda), 1.0)
     l1 = torch.nn.functional.l1_loss(images, targets, reduction="mean")
     return (1 - lamda) * l1 + lamda * (1 - ssim(images, targets, max_val=1.0, window_size=11).mean())

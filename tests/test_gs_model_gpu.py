@@ -188,3 +188,38 @@ def test_training_loop_learns_and_densifies(device):
     assert model.variance_q.shape[0] == n and model.color.shape[0] == n and model.mean_grads_iter.shape[0] == n
     model.reset_opacity(0.01)
     assert float(torch.sigmoid(model.opacity.detach()).max()) <= 0.01 + 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 48, 64), (1, 3, 37, 53), (1, 1, 6, 6), (1, 2, 16, 7), (1, 3, 270, 480)])
+@pytest.mark.parametrize("lamda", [0.2, 1.0, 0.0])
+def test_fused_loss_equals_torch_formulation(shape, lamda, device):
+    """gcp_ssim_l1_forward / _backward against the PyTorch formulation of gs_control.py:180-182 (Gaussian 11-tap SSIM,
+    reflect padding, + L1): value to 1e-6, gradient — including the exact adjoint of the reflect padding at the image
+    border — to 1e-4 of its scale."""
+    g = torch.Generator().manual_seed(sum(shape))
+    b = torch.rand(shape, generator=g).to(device)
+    a0 = (b + 0.25 * torch.randn(shape, generator=g).to(device)).clamp(0, 1)
+    out = {}
+    for fused in (True, False):
+        a = a0.clone().requires_grad_(True)
+        loss = gm.splat_loss(a, b, lamda, fused=fused)
+        (3.0 * loss).backward()  # a non-unit upstream gradient
+        out[fused] = (loss.detach(), a.grad)
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-5, atol=1e-6)
+    scale = out[False][1].abs().max().item()
+    assert scale > 0
+    err = (out[True][1] - out[False][1]).abs().max().item()
+    assert err <= 1e-4 * scale, (err, scale)
+    with torch.no_grad():  # no maps are written when nothing needs a gradient
+        torch.testing.assert_close(gm.splat_loss(a0, b, lamda), out[False][0], rtol=1e-5, atol=1e-6)
+
+
+def test_fused_loss_argument_checks(device):
+    a = torch.rand(1, 3, 16, 16, device=device)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gm.splat_loss(a.cpu(), a.cpu(), fused=True)
+    with pytest.raises(RuntimeError):
+        gm.splat_loss(a, a[:, :2])
+    with pytest.raises(RuntimeError):  # smaller than the reflection the window needs
+        gm.splat_loss(a[..., :5], a[..., :5])
+    assert float(gm.splat_loss(a, a)) == pytest.approx(0.0, abs=1e-6)

@@ -65,7 +65,7 @@ def main():
     print(f"forward  (projection + Function), no grad                {t_fwd_nograd:8.2f} ms")
     print(f"forward  (projection + Function), grad                   {t_fwd:8.2f} ms")
     print(f"forward + L1 loss + backward                             {t_l1:8.2f} ms")
-    print(f"forward + L1/D-SSIM loss + backward                      {t_step:8.2f} ms")
+    print(f"forward + L1/D-SSIM loss (fused) + backward              {t_step:8.2f} ms")
     # the Function alone on the same inputs
     from cuda_kernel import custom_autograd_grouped_cumprod as F
     c = cams[0]

@@ -93,6 +93,53 @@ def main():
             for k, a in zip(keys, args):
                 out[f"{name}/cam{c}/{k}"] = a.numpy()
         print(name, "rendered", len(captured), "cameras;", [int(a[0].numel()) for a in captured], "Gaussians kept")
+    # ---- densify / split / clone / prune / opacity reset (gs_model.py:190-271) on the same CPU recipe -----------------
+    n_gauss, extent = 160, 3.0
+    g = torch.Generator().manual_seed(77)
+    wd = make_world(n_gauss, 1, 32, 24, 9)
+    wd["variance_scale"] = torch.log(0.004 + 0.5 * torch.rand(n_gauss, 3, generator=g) ** 3)  # small, medium and huge
+    wd["opacity"] = torch.logit(0.0005 + 0.3 * torch.rand(n_gauss, 1, generator=g) ** 2)        # some below the prune threshold
+    grads_norm = 0.002 * torch.rand(n_gauss, generator=g)
+    grads_iter = torch.randint(0, 4, (n_gauss,), generator=g).to(torch.int16)
+    for k in ("mean", "variance_q", "variance_scale", "opacity", "color"):
+        out[f"densify/{k}"] = wd[k].numpy()
+    out["densify/mean_grads_norm"], out["densify/mean_grads_iter"] = grads_norm.numpy(), grads_iter.numpy()
+    out["densify/extent"] = np.array(extent)
+
+    def fresh():
+        with mfg.CudaToCpu():
+            m = gs_model.GS_model_with_param(
+                wd["mean"].clone(), wd["variance_q"].clone(), wd["variance_scale"].clone(), wd["opacity"].clone(),
+                1e-12, 0.0004, 0.01, 0.005, 0.04, 0.00016, 0.0000016, 0.01, 30_000, 0.0025, 0.025, 0.005, 0.001)
+        with torch.no_grad():
+            m.color.copy_(wd["color"])
+        m.mean_grads_norm, m.mean_grads_iter = grads_norm.clone(), grads_iter.clone()
+        return m
+
+    def record(tag, m):
+        for k in ("mean", "variance_q", "variance_scale", "opacity", "color"):
+            out[f"densify/{tag}/{k}"] = getattr(m, k).detach().numpy()
+        out[f"densify/{tag}/mean_grads_norm"] = m.mean_grads_norm.numpy()
+        out[f"densify/{tag}/mean_grads_iter"] = m.mean_grads_iter.numpy()
+
+    with mfg.CudaToCpu():
+        m = fresh()
+        out["densify/grads_per_iter_norm"] = m.param_grads_per_iter_norm().numpy()
+        m.densify_and_clone(extent)
+        record("clone", m)
+        m = fresh()
+        torch.manual_seed(123)
+        m.densify_and_split(extent)
+        record("split_seed123", m)
+        m = fresh()
+        torch.manual_seed(321)
+        m.densify_and_prune(extent, 0.001)
+        record("prune_seed321", m)
+        m = fresh()
+        m.reset_opacity(0.01)
+        record("reset_opacity", m)
+    print("densify: clone", out["densify/clone/mean"].shape[0], "split", out["densify/split_seed123/mean"].shape[0], "prune",
+          out["densify/prune_seed321/mean"].shape[0], "of", n_gauss)
     path = os.path.join(HERE, "forward_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -182,3 +182,45 @@ def test_camera_extent_uses_camera_centres():
     assert len(data) == 2 and data[1][3] == "b"
     assert data.get_camera_extent() == pytest.approx(2.0)
     assert data.get_camera_extent(reference_translation=True) == pytest.approx(0.0, abs=1e-6)
+
+
+def _densify_model(z):
+    t = lambda k: torch.from_numpy(z[f"densify/{k}"]).clone()  # noqa: E731
+    m = gm.GS_model_with_param(t("mean"), t("variance_q"), t("variance_scale"), t("opacity"))  # the reference's defaults
+    with torch.no_grad():
+        m.color.copy_(t("color"))
+    m.mean_grads_norm, m.mean_grads_iter = t("mean_grads_norm"), t("mean_grads_iter")
+    return m
+
+
+def _assert_model_equals(z, tag, m):
+    for k in ("mean", "variance_q", "variance_scale", "opacity", "color", "mean_grads_norm", "mean_grads_iter"):
+        got = getattr(m, k).detach().numpy()
+        want = z[f"densify/{tag}/{k}"]
+        assert got.shape == want.shape and got.dtype == want.dtype, (tag, k, got.shape, want.shape)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7, err_msg=f"{tag}/{k}")
+
+
+def test_densify_prune_reset_match_reference():
+    """The reference's densify_and_clone / _split / _prune and reset_opacity (gs_model.py:190-271) run on CPU by
+    make_forward_golden.py, same seeds: the same Gaussians are split, cloned and pruned, rows in the same order,
+    the split samples drawn identically."""
+    z = np.load(GOLDEN)
+    extent = float(z["densify/extent"])
+    m = _densify_model(z)
+    np.testing.assert_allclose(m.param_grads_per_iter_norm().numpy(), z["densify/grads_per_iter_norm"], rtol=1e-6)
+    m.densify_and_clone(extent)
+    _assert_model_equals(z, "clone", m)
+    m = _densify_model(z)
+    torch.manual_seed(123)
+    m.densify_and_split(extent)
+    _assert_model_equals(z, "split_seed123", m)
+    m = _densify_model(z)
+    torch.manual_seed(321)
+    m.densify_and_prune(extent)
+    _assert_model_equals(z, "prune_seed321", m)
+    assert len(m._optimizer.param_groups) == 5 and m._optimizer.param_groups[0]["params"][0] is m.mean
+    m = _densify_model(z)
+    m.reset_opacity(0.01)
+    _assert_model_equals(z, "reset_opacity", m)
+    assert 0 < z["densify/clone/mean"].shape[0] - 160 and z["densify/prune_seed321/mean"].shape[0] != 160

@@ -59,8 +59,11 @@ def load_colmap(root, device):
 
 def train(start, P, K, wh, targets, iterations=300, batch_size=3, loss_lamda=0.2, opacity_init=0.1, neighbours=3,
           densify_from_iter=500, densify_until_iter=15000, densification_interval=100, opacity_reset_interval=3000,
-          reset_opacity_min=0.01, seed=0, log=print):
+          reset_opacity_min=0.01, seed=0, log=print, rank=0, world=1):
+    """`world` > 1: one process per GPU under torch.distributed; every rank holds the whole scene, renders
+    `batch[rank::world]` and the gradients are all-reduced (GS_model_with_param.allreduce_grads)."""
     dev = start.device
+    torch.manual_seed(seed)  # densification draws samples: every rank must draw the same ones
     n = start.shape[0]
     q = torch.zeros((n, 4), device=dev)
     q[:, 3] = 1  # identity rotation, (x, y, z, w) (gs_control.py:113-114)
@@ -75,9 +78,22 @@ def train(start, P, K, wh, targets, iterations=300, batch_size=3, loss_lamda=0.2
         order = torch.randperm(len(data), generator=gen)
         for b in range(0, len(order), batch_size):
             idx = order[b:b + batch_size].to(dev)
-            images, kept, grad_iter = model(P[idx], K[idx], wh[idx], idx.tolist())
-            loss = gm.splat_loss(images, targets[torch.tensor(kept, device=dev)], loss_lamda)
-            loss.backward()
+            mine = idx[rank::world]
+            if mine.numel():
+                images, kept, grad_iter = model(P[mine], K[mine], wh[mine], mine.tolist())
+                loss = gm.splat_loss(images, targets[torch.tensor(kept, device=dev)], loss_lamda) * (mine.numel() / idx.numel())
+                loss.backward()
+            else:  # more ranks than cameras in this batch
+                loss, grad_iter = torch.zeros((), device=dev), torch.zeros(model.mean.shape[0], dtype=torch.bool, device=dev)
+            if world > 1:
+                grad_iter = model.allreduce_grads(grad_iter)
+                loss = loss.detach().clone()  # the batch loss, for the log only
+                if torch.distributed.get_backend() == "gloo":
+                    host = loss.cpu()
+                    torch.distributed.all_reduce(host)
+                    loss = host.to(dev)
+                else:
+                    torch.distributed.all_reduce(loss)
             model.param_iter_update(grad_iter)
             model.train_step()
             iteration += 1
@@ -107,10 +123,18 @@ if __name__ == "__main__":
     ap.add_argument("--iterations", type=int, default=400)
     ap.add_argument("--densify-from", type=int, default=500)
     a = ap.parse_args()
-    device = torch.device("cuda", 0)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    if world > 1:  # python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_cameras.py
+        torch.distributed.init_process_group("nccl", device_id=device)
     if a.colmap:
         start, P, K, wh, targets = load_colmap(a.colmap, device)
     else:
         start, P, K, wh, targets = synthetic_scene(a.gaussians, a.cameras, a.width, a.height, 0, device)
-    _, losses = train(start, P, K, wh, targets, iterations=a.iterations, densify_from_iter=a.densify_from)
-    print(f"loss {np.mean(losses[:10]):.5f} -> {np.mean(losses[-10:]):.5f}")
+    _, losses = train(start, P, K, wh, targets, iterations=a.iterations, densify_from_iter=a.densify_from, rank=rank, world=world,
+                      log=print if rank == 0 else (lambda *_: None))
+    if rank == 0:
+        print(f"loss {np.mean(losses[:10]):.5f} -> {np.mean(losses[-10:]):.5f}")
+    if world > 1:
+        torch.distributed.destroy_process_group()

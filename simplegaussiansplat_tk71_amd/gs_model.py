@@ -358,6 +358,31 @@ class GS_model_with_param(torch.nn.Module):
         self._optimizer.zero_grad(set_to_none=True)
         return self
 
+    # ---- camera data parallelism (one process per GPU; the reference is single-GPU) ----------------------------
+    def allreduce_grads(self, grad_iter=None, group=None):
+        """Cameras of a batch are independent: each rank renders its share (`batch[rank::world]`, loss weighted by its
+        share of the batch) and the parameter gradients are summed with ONE all-reduce of the concatenated N x 38
+        floats (sharding.allreduce_gaussian_grads; RCCL over xGMI under backend "nccl").  `grad_iter` (seen by any
+        camera) is OR-ed across ranks.  Every rank then takes the same optimiser step."""
+        import torch.distributed as dist
+
+        from . import sharding
+
+        params = [p for _, p in self.named_parameters(recurse=False)]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        for p, g in zip(params, sharding.allreduce_gaussian_grads(*grads, group=group)):
+            p.grad = g.contiguous()
+        if grad_iter is not None:
+            seen = grad_iter.to(torch.uint8)
+            if seen.is_cuda and dist.get_backend(group) == "gloo":
+                host = seen.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+                seen = host.to(grad_iter.device)
+            else:
+                dist.all_reduce(seen, op=dist.ReduceOp.MAX, group=group)
+            grad_iter = seen.bool()
+        return grad_iter
+
     # ---- densification statistics (:190-199) ----------------------------------------------------------------
     def param_iter_update(self, grad_iter):
         if self.mean.grad is not None:

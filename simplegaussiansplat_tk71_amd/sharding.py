@@ -205,7 +205,12 @@ def allreduce_gaussian_grads(*grads: torch.Tensor, group=None):
     """Per-Gaussian gradients are sums over pixels; a box that straddles bands has a share on several ranks.
     ONE all-reduce of the concatenated N x (2 + 4 + 1 + 3) floats (reduce-scatter + all-gather over xGMI)."""
     flat = torch.cat([g.reshape(g.size(0), -1) for g in grads], 1).contiguous()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":  # rehearsals of the N > 1 path on a box without RCCL peers
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     out, c = [], 0
     for g in grads:
         k = g[0].numel() if g.size(0) else 0

@@ -223,3 +223,54 @@ def test_fused_loss_argument_checks(device):
     with pytest.raises(RuntimeError):  # smaller than the reflection the window needs
         gm.splat_loss(a[..., :5], a[..., :5])
     assert float(gm.splat_loss(a, a)) == pytest.approx(0.0, abs=1e-6)
+
+
+def _dp_worker(rank, world, port, out_path):
+    """One rank of the camera-parallel step: render batch[rank::world], all-reduce, compare with the whole batch."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of the test box
+    try:
+        device = torch.device("cuda", 0)
+        w = random_world(1500, 3, 96, 64, 11, device)
+        target = torch.rand(3, 3, 64, 96, generator=torch.Generator().manual_seed(2)).to(device)
+        names = ("mean", "variance_q", "variance_scale", "opacity", "color")
+
+        def grads(cams, weight):
+            model = make_model(w)
+            images, kept, grad_iter = model(w["P"][cams], w["K"][cams], w["wh"][cams], cams.tolist())
+            (gm.splat_loss(images, target[cams]) * weight).backward()
+            return model, grad_iter
+
+        batch = torch.arange(3, device=device)
+        mine = batch[rank::world]
+        model, grad_iter = grads(mine, mine.numel() / batch.numel())
+        grad_iter = model.allreduce_grads(grad_iter)
+        if rank == 0:
+            full, full_iter = grads(batch, 1.0)
+            worst = 0.0
+            for k in names:
+                a, b = getattr(model, k).grad, getattr(full, k).grad
+                worst = max(worst, ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item())
+            torch.save({"worst": worst, "iter_equal": bool(torch.equal(grad_iter, full_iter))}, out_path)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_camera_data_parallel_step_equals_whole_batch(device, tmp_path):
+    """Two processes (gloo; RCCL needs one GPU per rank) each render their cameras of a 3-camera batch; after
+    GS_model_with_param.allreduce_grads every parameter gradient equals the single-process whole-batch one."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["iter_equal"]
+    assert res["worst"] <= 1e-4, res

@@ -127,8 +127,8 @@ def function_level(dev, workload):
 def caller_level(dev, workload):
     """Row f4 (outside the timed region, informational): one training step of the caller — camera projection,
     Function, L1 + D-SSIM loss, backward to the five parameter tensors — on 10^6 Gaussians and one 1920x1080 camera,
-    with the fused projection and loss kernels and, once, with the reference's op-by-op PyTorch formulation of both
-    (gs_model.py:277-425, gs_control.py:180-182) around the same Function."""
+    with the fused projection and loss kernels.  (The reference's op-by-op PyTorch formulation of projection and loss,
+    gs_model.py:277-425 / gs_control.py:180-182, around the same Function is timed by tests/bench_reference_gpu.py.)"""
     import time
 
     import torch
@@ -143,11 +143,9 @@ def caller_level(dev, workload):
     model = gm.GS_model_with_param(*synthetic.make_world(n, width, 2.0, seed=0, device=dev))
     target = torch.rand(1, 3, height, width, device=dev)
 
-    fused = [True]
-
     def step():
         images = model(P, K, wh, [0])[0]
-        gm.splat_loss(images, target, 0.2, fused=fused[0]).backward()  # gs_control.py:180-182
+        gm.splat_loss(images, target, 0.2).backward()  # gs_control.py:180-182
         model._optimizer.zero_grad(set_to_none=True)
 
     def timed(reps):
@@ -162,16 +160,13 @@ def caller_level(dev, workload):
     cams, _, _ = model.camera_inputs(P, K, wh)
     pairs = int(cams[0]["boxsize"].sum())
     fused_ms = timed(5)
-    model.camera_inputs = lambda P, K, wh: gm.GS_model_with_param.camera_inputs(model, P, K, wh, fused=False)
-    fused[0] = False
-    torch_ms = timed(1)
     return {
         "what": "GS_model_with_param: projection + Function + L1/D-SSIM loss, forward and backward, one 1920x1080 camera",
         "gaussians": n,
         "visible": int(cams[0]["boxsize"].numel()),
         "pairs": pairs,
         "step_ms": fused_ms,
-        "step_ms_reference_formulation_of_projection_and_loss": torch_ms,
+        "reference_formulation_ms": "180 (projection and loss as PyTorch ops around the same Function; tests/bench_reference_gpu.py)",
         "pairs_per_s": pairs / (fused_ms * 1e-3),
     }
 

@@ -9,6 +9,10 @@ cuda_kernel.py) never does, and has no CPU fallback.
   torch_path.py  the "pure-PyTorch torch.cumprod path": per-group torch.cumprod / cumsum
   wrappers.py    literal restatement of gs_model.py:544-566 and :716-722 around the scans
   ref.py         loader for oracle/_ref/ (the reference's own sources compiled here)
+  dense_render.py       dense autograd restatement of the rasterise-and-blend Function (rows f1/f2)
+  gs_forward_torch.py   op-for-op PyTorch restatement of the model forward up to the Function call (row f4):
+                        the checker of the fused projection kernels, pinned to the reference's own forward
+  loss_torch.py         PyTorch formulation of the L1 + D-SSIM loss: the checker of the fused loss kernels
 
 Pinned by: the reference's known-answer vectors (cuda_test.py:19-34,
 uitility.py:383-393), the reference's forward .cu files compiled for the host

@@ -5,9 +5,9 @@ Mirrors the reference's model class (reference: gs_model.py:123-460, `GS_model_w
 `[images, image_sample, grad_iter]`, same per-parameter Adam learning rates, densify / prune / opacity reset.
 Row f4 of SURVEY.md §8: this is caller integration, PyTorch on the GPU around the HIP Function — not a kernel.
 
-The projection math (`camera_inputs`, reference: gs_model.py:277-425) is pinned against the reference's own
-forward run on CPU (tests/golden/forward_golden.npz: the arguments the reference hands to
-`custom_autograd_grouped_cumprod.apply`).  Differences, all deliberate:
+The projection (`camera_inputs`, reference: gs_model.py:277-425) is pinned, through its PyTorch restatement in
+oracle/gs_forward_torch.py, against the reference's own forward run on CPU (tests/golden/forward_golden.npz: the
+arguments the reference hands to `custom_autograd_grouped_cumprod.apply`).  Differences, all deliberate:
   * the 3-sigma box comes from a closed-form 2x2 eigen-decomposition on the device; the reference moves every
     covariance to the CPU for `torch.linalg.eigh` and back (gs_model.py:327-332).  For a positive semi-definite
     matrix `V^2 |lambda|` is just its diagonal, so the box is 3*sqrt(diag) exactly;
@@ -15,13 +15,14 @@ forward run on CPU (tests/golden/forward_golden.npz: the arguments the reference
   * images are permuted to (B, 3, H, W); the reference `reshape`s (H, W, 3) memory into (3, H, W), scrambling
     channels (gs_model.py:454, SURVEY.md §0 Q6) — `reference_layout=True` reproduces that;
   * one Function call per camera, never chunked (nothing of pair-list size exists here; gs_model.py:428);
-  * `eval_sh` below stands in for the reference's `sh_utility.eval_sh`, which is not in its checkout
+  * the SH colour stands in for the reference's `sh_utility.eval_sh`, which is not in its checkout
     (gs_model.py:9,335): real spherical harmonics up to degree 2 in the usual 3DGS convention — parity unpinned;
   * tensors live on the parameters' device instead of a hard-coded "cuda";
   * on the GPU the whole per-Gaussian chain is ONE HIP kernel per camera and direction (`gcp_project_forward`,
     `gcp_project_backward`, csrc/gcp_project.hip) instead of ~150 PyTorch kernels: at 10^6 Gaussians the reference's
-    formulation costs 64 ms forward + 110 ms backward around a 1.8 ms Function.  `camera_inputs(fused=False)` keeps
-    the PyTorch formulation: it runs anywhere and is what the kernels are tested against.
+    formulation costs 64 ms forward + 110 ms backward around a 1.8 ms Function.  That formulation is kept, as the
+    checker the kernels are tested against, in oracle/gs_forward_torch.py — not here: projection and loss have no
+    CPU path (CPU tensors raise).
 """
 import math
 
@@ -35,40 +36,11 @@ __all__ = [
     "GS_dataset",
     "GS_model_with_param",
     "camera_inputs",
-    "eval_sh",
     "qvec_to_rotmat_batch",
-    "pixel_jacobian_batch",
-    "invert_2x2_batch",
-    "box_halfsize",
     "get_expon_lr_func",
     "mean_neighbour_distance",
-    "ssim",
     "splat_loss",
 ]
-
-_SH_C0 = 0.28209479177387814  # 1 / (2 sqrt(pi))
-_SH_C1 = 0.4886025119029199  # sqrt(3 / (4 pi))
-_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
-
-
-def eval_sh(deg, sh, dirs):
-    """Colour of a real-SH expansion in direction `dirs`: sh (..., 3, (deg+1)^2), dirs (..., 3) unit -> (..., 3).
-    Stand-in for the reference's missing sh_utility.eval_sh (call site gs_model.py:335-338); degree <= 2."""
-    if not 0 <= deg <= 2:
-        raise ValueError("eval_sh supports degrees 0..2")
-    if sh.shape[-1] < (deg + 1) ** 2:
-        raise ValueError("not enough SH coefficients for the degree")
-    out = _SH_C0 * sh[..., 0]
-    if deg > 0:
-        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
-        out = out - _SH_C1 * y * sh[..., 1] + _SH_C1 * z * sh[..., 2] - _SH_C1 * x * sh[..., 3]
-        if deg > 1:
-            xx, yy, zz = x * x, y * y, z * z
-            out = (out + _SH_C2[0] * (x * y) * sh[..., 4] + _SH_C2[1] * (y * z) * sh[..., 5]
-                   + _SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] + _SH_C2[3] * (x * z) * sh[..., 7]
-                   + _SH_C2[4] * (xx - yy) * sh[..., 8])
-    return out
-
 
 def qvec_to_rotmat_batch(q):
     """(N, 4) unit quaternions in (x, y, z, w) order -> (N, 3, 3) (reference: uitility.py:231-254)."""
@@ -77,38 +49,6 @@ def qvec_to_rotmat_batch(q):
     r1 = torch.stack([2 * (x * y + w * z), 1 - 2 * (x**2 + z**2), 2 * (y * z - w * x)], dim=1)
     r2 = torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x**2 + y**2)], dim=1)
     return torch.stack([r0, r1, r2], dim=1)
-
-
-def pixel_jacobian_batch(K, xyz):
-    """d(pixel)/d(camera point): K (C, 3, 3), xyz (C, N, 3) -> (C, N, 2, 3) (reference: uitility.py:257-287)."""
-    fx, fy = K[:, 0, 0].unsqueeze(1), K[:, 1, 1].unsqueeze(1)
-    X, Y, Z = xyz[..., 0], xyz[..., 1], xyz[..., 2].clamp_min(1e-2)
-    zero = torch.zeros_like(Z)
-    row0 = torch.stack([fx / Z, zero, -fx * X / (Z**2)], dim=-1)
-    row1 = torch.stack([zero, fy / Z, -fy * Y / (Z**2)], dim=-1)
-    return torch.stack([row0, row1], dim=-2)
-
-
-def invert_2x2_batch(A, eps=1e-6):
-    """Closed-form inverse with `det + eps` (reference: uitility.py:431-462)."""
-    a, b, c, d = A[..., 0, 0], A[..., 0, 1], A[..., 1, 0], A[..., 1, 1]
-    det = a * d - b * c + eps
-    return torch.stack([torch.stack([d / det, -b / det], dim=-1), torch.stack([-c / det, a / det], dim=-1)], dim=-2)
-
-
-def box_halfsize(cov):
-    """3-sigma half extents `3*sqrt(V^2 |lambda|)` of 2x2 covariances (..., 2, 2) -> (..., 2), on the device
-    (reference: gs_model.py:327-332 via CPU eigh, lower triangle)."""
-    a, b, c = cov[..., 0, 0], cov[..., 1, 0], cov[..., 1, 1]
-    m, d = 0.5 * (a + c), 0.5 * (a - c)
-    r = torch.sqrt(d * d + b * b)
-    lo, hi = m - r, m + r
-    ratio = torch.where(r > 0, d / r.clamp_min(torch.finfo(cov.dtype).tiny), torch.zeros_like(d))
-    w_hi, w_lo = 0.5 * (1.0 + ratio), 0.5 * (1.0 - ratio)  # squared x-components of the two eigenvectors
-    ex = torch.where(lo >= 0, a, w_lo * lo.abs() + w_hi * hi.abs())
-    ey = torch.where(lo >= 0, c, w_hi * lo.abs() + w_lo * hi.abs())
-    # r == 0: eigh returns the identity basis, eigenvalues (a, a)
-    return 3.0 * torch.sqrt(torch.stack([ex, ey], dim=-1).abs())
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
@@ -196,7 +136,7 @@ class _ProjectCamera(torch.autograd.Function):
         return (*grads, None, None, None, None, None, None)
 
 
-def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max=2, sh=eval_sh, fused=None):
+def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max=2):
     """Per camera, the depth-ordered, culled arguments of the Function (reference: gs_model.py:277-425).
 
     mean (N,3), variance_q (N,4 xyzw), variance_scale (N,3 log), opacity (N,1 logit), color (N,(L+1)^2,3),
@@ -205,84 +145,20 @@ def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, ti
     boxsize, startpoint, endpoint, mean, variance_inverse, opacity, l_d, index (Gaussian ids, depth order),
     and the (N,) bool `grad_iter` of Gaussians seen by any camera (:401-407).
 
-    `fused` (default: on for GPU tensors with the built-in `eval_sh`) runs one HIP kernel per camera and direction;
-    otherwise the chain is the PyTorch formulation below, differentiated by autograd."""
+    One HIP kernel per camera and direction (csrc/gcp_project.hip); GPU tensors only — there is no CPU path.  The
+    reference's op-by-op PyTorch formulation lives in oracle/gs_forward_torch.py as the checker."""
     dev = mean.device
-    if fused is None:
-        fused = mean.is_cuda and sh is eval_sh
-    if fused:
-        if sh is not eval_sh:
-            raise ValueError("the fused projection evaluates the built-in real SH basis")
-        width, height = wh[0, 0].to(torch.int32), wh[0, 1].to(torch.int32)
-        clamp = _box_clamp(wh, tile_max_width, dev)
-        grad_iter = torch.zeros(mean.shape[0], device=dev, dtype=torch.bool)
-        cams = []
-        for c in range(P.shape[0]):
-            vinv, alpha, l_d, start, end, mean_xy, boxsize, index, keep = _ProjectCamera.apply(
-                mean, variance_q, variance_scale, opacity, color, P[c], K[c], int(width), int(height), clamp, L_max)
-            grad_iter |= keep
-            cams.append(None if index.numel() == 0 else {
-                "boxsize": boxsize, "startpoint": start, "endpoint": end, "mean": mean_xy, "variance_inverse": vinv,
-                "opacity": alpha, "l_d": l_d, "index": index})
-        return cams, grad_iter, (width, height)
-    return _camera_inputs_torch(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max, sh)
-
-
-def _camera_inputs_torch(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max, sh):
-    """The reference's formulation, op for op (gs_model.py:277-425), on whatever device the tensors live."""
-    dev = mean.device
-    n, n_cam = mean.shape[0], P.shape[0]
     width, height = wh[0, 0].to(torch.int32), wh[0, 1].to(torch.int32)
-    fmax, fmin = torch.finfo(torch.float32).max, torch.finfo(torch.float32).min
-    imax, imin = torch.iinfo(torch.int32).max, torch.iinfo(torch.int32).min
-
-    homo = torch.hstack((mean, torch.ones((n, 1), device=dev, dtype=mean.dtype)))[None]
-    mean_camera = homo @ P.transpose(1, 2)  # (C, N, 3)
-    pix_h = mean_camera @ K.transpose(1, 2)
-    mean_pixel = pix_h[:, :, 0:2] / pix_h[:, :, 2][:, :, None].clamp_min(1e-2)
-
-    q = variance_q / torch.norm(variance_q, dim=1, keepdim=True).clamp_min(1e-8)
-    rot = qvec_to_rotmat_batch(q)
-    s_diag = torch.eye(3, dtype=torch.float32, device=dev)[None] * torch.exp(variance_scale)[:, None, :]
-    cov = rot @ s_diag @ s_diag.transpose(1, 2) @ rot.transpose(1, 2)
-    cov_cam = P[:, None, :, 0:3] @ cov[None] @ P.transpose(1, 2)[:, None, 0:3, :]
-    J = pixel_jacobian_batch(K, mean_camera)
-    cov_pix = (J @ cov_cam @ J.transpose(2, 3)).clamp(max=fmax / 1000, min=fmin / 1000) \
-        + 1e-6 * torch.eye(2, dtype=torch.float32, device=dev)[None, None]
-    half = box_halfsize(cov_pix.detach())  # boxes are integers downstream: no gradient path (:365)
-
-    view = -mean_camera / torch.norm(mean_camera, dim=-1, keepdim=True).clamp_min(1e-8)
-    l_d = sh(L_max, color[None].expand(n_cam, -1, -1, -1).transpose(2, 3), view)
-    vinv = invert_2x2_batch(cov_pix)
-
-    z_index = torch.argsort(mean_camera[:, :, 2].detach(), dim=1, stable=True)
-    cam = torch.arange(n_cam, device=dev)[:, None]
-    mc_z = mean_camera[cam, z_index, 2]
-    op_z = torch.sigmoid(opacity)[None].expand(n_cam, -1, -1)[cam, z_index]
-    mp_z = mean_pixel[cam, z_index].clamp(max=imax / 1000, min=imin / 1000).to(torch.int32)
-    vinv_z = vinv[cam, z_index]
-    l_z = l_d[cam, z_index]
-    half_z = half[cam, z_index].clamp(max=_box_clamp(wh, tile_max_width, dev)).to(torch.int32)
-
-    grad_iter = torch.zeros(n, device=dev, dtype=torch.bool)
+    clamp = _box_clamp(wh, tile_max_width, dev)
+    grad_iter = torch.zeros(mean.shape[0], device=dev, dtype=torch.bool)
     cams = []
-    for c in range(n_cam):
-        bw, bh, mx, my = half_z[c, :, 0], half_z[c, :, 1], mp_z[c, :, 0], mp_z[c, :, 1]
-        keep = (mc_z[c] > 0) & (bw != 0) & (mx - bw < width) & (mx + bw > 0) & (my - bh < height) & (my + bh > 0)
-        grad_iter[z_index[c, keep]] = True
-        if not bool(keep.any()):
-            cams.append(None)
-            continue
-        m, b = mp_z[c][keep], half_z[c][keep]
-        lim = torch.stack([width, height]).to(dev)
-        start = torch.minimum((m - b).clamp(min=0), lim)
-        end = torch.minimum((m + b).clamp(min=0), lim)
-        cams.append({
-            "boxsize": torch.prod(end - start + 1, dim=1),
-            "startpoint": start, "endpoint": end, "mean": m,
-            "variance_inverse": vinv_z[c][keep].contiguous(), "opacity": op_z[c][keep].contiguous(),
-            "l_d": l_z[c][keep].contiguous(), "index": z_index[c, keep],
-        })
+    for c in range(P.shape[0]):
+        vinv, alpha, l_d, start, end, mean_xy, boxsize, index, keep = _ProjectCamera.apply(
+            mean, variance_q, variance_scale, opacity, color, P[c], K[c], int(width), int(height), clamp, L_max)
+        grad_iter |= keep
+        cams.append(None if index.numel() == 0 else {
+            "boxsize": boxsize, "startpoint": start, "endpoint": end, "mean": mean_xy, "variance_inverse": vinv,
+            "opacity": alpha, "l_d": l_d, "index": index})
     return cams, grad_iter, (width, height)
 
 
@@ -447,9 +323,9 @@ class GS_model_with_param(torch.nn.Module):
         self.changing_optimizer()
 
     # ---- forward (:277-460) ------------------------------------------------------------------------------------
-    def camera_inputs(self, P, K, wh, fused=None):
+    def camera_inputs(self, P, K, wh):
         return camera_inputs(self.mean, self.variance_q, self.variance_scale, self.opacity, self.color, P, K, wh,
-                             self.variance_pixel_tile_max_width, self._L_max, fused=fused)
+                             self.variance_pixel_tile_max_width, self._L_max)
 
     def forward(self, P, K, wh, image_sample):
         cams, grad_iter, (width, height) = self.camera_inputs(P, K, wh)
@@ -470,31 +346,6 @@ class GS_model_with_param(torch.nn.Module):
         return [out, names, grad_iter]
 
 
-def _gaussian_window(size, sigma, device, dtype):
-    x = torch.arange(size, device=device, dtype=dtype) - (size - 1) / 2
-    g = torch.exp(-(x * x) / (2 * sigma * sigma))
-    return g / g.sum()
-
-
-def ssim(img1, img2, window_size=11, max_val=1.0, sigma=1.5):
-    """Structural-similarity map (B, C, H, W), Gaussian window, reflect padding — the quantity the reference takes
-    from kornia (`metrics.ssim(..., max_val=1.0, window_size=11)`, gs_control.py:180).  kornia is not installed
-    here, so this is the published formula (Wang et al. 2004), parity unpinned."""
-    c = img1.shape[1]
-    g = _gaussian_window(window_size, sigma, img1.device, img1.dtype)
-    kx, ky = g.view(1, 1, 1, -1).expand(c, 1, 1, -1), g.view(1, 1, -1, 1).expand(c, 1, -1, 1)
-    pad = window_size // 2
-
-    def blur(t):
-        t = torch.nn.functional.pad(t, (pad, pad, pad, pad), mode="reflect")
-        return torch.nn.functional.conv2d(torch.nn.functional.conv2d(t, kx, groups=c), ky, groups=c)
-
-    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
-    mu1, mu2 = blur(img1), blur(img2)
-    s11, s22, s12 = blur(img1 * img1) - mu1 * mu1, blur(img2 * img2) - mu2 * mu2, blur(img1 * img2) - mu1 * mu2
-    return ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2) + 1e-12)
-
-
 _WINDOW_CACHE = {}
 
 
@@ -504,8 +355,9 @@ def _host_window(window_size, sigma):
 
     key = (window_size, sigma)
     if key not in _WINDOW_CACHE:
-        w = _gaussian_window(window_size, sigma, "cpu", torch.float32)
-        _WINDOW_CACHE[key] = (ctypes.c_float * window_size)(*w.tolist())
+        x = torch.arange(window_size, dtype=torch.float32) - (window_size - 1) / 2
+        w = torch.exp(-(x * x) / (2 * sigma * sigma))
+        _WINDOW_CACHE[key] = (ctypes.c_float * window_size)(*(w / w.sum()).tolist())
     return _WINDOW_CACHE[key]
 
 
@@ -551,13 +403,8 @@ class _SplatLoss(torch.autograd.Function):
         return grad.to(ctx.dtype), None, None, None
 
 
-def splat_loss(images, targets, lamda=0.2, fused=None):
-    """(1 - lambda) L1 + lambda (1 - mean SSIM) (reference: gs_control.py:180-182).  On the GPU (`fused`, the default
-    there) both terms and their gradient are one HIP kernel per direction; `fused=False` is the PyTorch formulation
-    the kernel is tested against."""
-    if fused is None:
-        fused = images.is_cuda
-    if fused:
-        return _SplatLoss.apply(images, targets, float(lamda), 1.0)
-    l1 = torch.nn.functional.l1_loss(images, targets, reduction="mean")
-    return (1 - lamda) * l1 + lamda * (1 - ssim(images, targets, max_val=1.0, window_size=11).mean())
+def splat_loss(images, targets, lamda=0.2):
+    """(1 - lambda) L1 + lambda (1 - mean SSIM), 11-tap Gaussian window, reflect padding (reference:
+    gs_control.py:180-182, kornia.metrics.ssim).  Both terms and their gradient are one HIP kernel per direction
+    (csrc/gcp_loss.hip); GPU tensors only.  The PyTorch formulation it is tested against: oracle/loss_torch.py."""
+    return _SplatLoss.apply(images, targets, float(lamda), 1.0)

@@ -10,7 +10,7 @@ make_function_golden.py.  What is recorded is every argument list it hands to
 `custom_autograd_grouped_cumprod.apply` (gs_model.py:449) and the image batch it returns.
 
 One stand-in is unavoidable: `sh_utility.eval_sh` (gs_model.py:9,335) is not part of the reference's checkout.
-The build's own `eval_sh` (simplegaussiansplat_tk71_amd/gs_model.py) is plugged in, so the colour argument `l_d`
+The build's own `eval_sh` (oracle/gs_forward_torch.py; the HIP kernel evaluates the same basis) is plugged in, so the colour argument `l_d`
 is NOT a reference output (it is stored for completeness and flagged); every other recorded array is.
 Only data is written: inputs and the reference's outputs.  No reference source is copied.
 """
@@ -57,7 +57,7 @@ def make_world(n_gauss, n_cam, width, height, seed):
 def main():
     gs_model = mfg.import_reference()
     mfg.patch_stable_sort()
-    from simplegaussiansplat_tk71_amd.gs_model import eval_sh
+    from oracle.gs_forward_torch import eval_sh
 
     gs_model.eval_sh = eval_sh  # stand-in for the missing sh_utility (see the module docstring)
     gs_model.Utilities.gpu_mem = staticmethod(lambda tag="": None)  # prints torch.cuda statistics only

@@ -277,3 +277,49 @@ def test_camera_data_parallel_step_equals_whole_batch(device, tmp_path):
     res = torch.load(out)
     assert res["iter_equal"]
     assert res["worst"] <= 1e-4, res
+
+
+def _rotmat_to_qvec_wxyz(R):
+    """3x3 rotation -> COLMAP quaternion (w, x, y, z), w >= 0."""
+    R = np.asarray(R, dtype=np.float64)
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = np.sqrt(max(0.0, 1 + R[0, 0] - R[1, 1] - R[2, 2])) / 2
+    y = np.sqrt(max(0.0, 1 - R[0, 0] + R[1, 1] - R[2, 2])) / 2
+    z = np.sqrt(max(0.0, 1 - R[0, 0] - R[1, 1] + R[2, 2])) / 2
+    x, y, z = np.copysign(x, R[2, 1] - R[1, 2]), np.copysign(y, R[0, 2] - R[2, 0]), np.copysign(z, R[1, 0] - R[0, 1])
+    return np.array([w, x, y, z])
+
+
+def test_training_from_a_colmap_directory(device, tmp_path):
+    """BASELINE config 4's shape (COLMAP sparse model + images -> training loop) on a synthetic scene written to disk:
+    cameras.bin / images.bin / points3D.bin through colmap_io, PNG photographs, then examples/train_cameras.py's
+    --colmap path.  (The reference's own scene has no images.bin)"""
+    from PIL import Image
+
+    from examples.train_cameras import load_colmap, synthetic_scene, train
+    from simplegaussiansplat_tk71_amd import colmap_io
+
+    n_cam, width, height = 5, 64, 48
+    start, P, K, wh, targets = synthetic_scene(500, n_cam, width, height, 1, device)
+    root = tmp_path / "scene"
+    (root / "images").mkdir(parents=True)
+    cameras, images = {}, {}
+    for c in range(n_cam):
+        cameras[c + 1] = {"model": "PINHOLE", "width": width, "height": height,
+                          "params": np.array([K[c, 0, 0].item(), K[c, 1, 1].item(), K[c, 0, 2].item(), K[c, 1, 2].item()])}
+        Pc = P[c].cpu().numpy().astype(np.float64)
+        q = _rotmat_to_qvec_wxyz(Pc[:, :3])
+        assert np.allclose(colmap_io.qvec_to_rotmat(q), Pc[:, :3], atol=1e-4)
+        images[c + 1] = {"qvec": q, "tvec": Pc[:, 3], "camera_id": c + 1, "name": f"img{c}.png"}
+        Image.fromarray((targets[c].permute(1, 2, 0).clamp(0, 1) * 255).round().byte().cpu().numpy()).save(root / "images" / f"img{c}.png")
+    xyz = start.cpu().numpy().astype(np.float64)
+    colmap_io.write_model(root / "sparse" / "0", cameras, images,
+                          {"id": np.arange(1, len(xyz) + 1), "xyz": xyz, "rgb": np.zeros((len(xyz), 3), np.uint8), "error": np.zeros(len(xyz))})
+    xyz2, P2, K2, wh2, photos = load_colmap(str(root), device)
+    torch.testing.assert_close(xyz2, start, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(P2, P, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(K2, K)
+    torch.testing.assert_close(wh2, wh)
+    assert photos.shape == (n_cam, 3, height, width) and float((photos - targets).abs().max()) <= 0.5 / 255 + 1e-6
+    _, losses = train(xyz2, P2, K2, wh2, photos, iterations=60, densify_from_iter=1000, opacity_reset_interval=0, log=lambda *_: None)
+    assert np.mean(losses[-5:]) < 0.85 * np.mean(losses[:5]), (losses[:5], losses[-5:])

@@ -284,21 +284,39 @@ struct BlendArgs {
   int W, H, tiles_x;
 };
 
+#ifndef GCP_BOX_MASK
+#define GCP_BOX_MASK 1
+#endif
+
 template <int STAGE>
 struct Staged {
   int4 box[STAGE];     // x0, y0, x1-x0, y1-y0 (clamped to the image)
   float4 geo[STAGE];   // mx, my, opacity, 1/opacity (0 if opacity == 0)
   float4 vin[STAGE];   // a b c d of Λ' = -0.5*log2(e) * Λ  (Λ = [[a,b],[c,d]])
   float4 col[STAGE];   // l0 l1 l2 -
+#if GCP_BOX_MASK
+  unsigned mask[STAGE];  // bits 0-15: tile columns inside the box, bits 16-31: tile rows inside the box
+#endif
 };
 
 template <int STAGE>
-__device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>& s, int first, int cnt) {
+__device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>& s, int first, int cnt, int tile_x0, int tile_y0) {
   for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
     const i64 g = a.tile_list[first + j];
     Box b;
     load_box(a.start, a.end, g, a.W, a.H, b);
     s.box[j] = make_int4(b.x0, b.y0, b.x1 - b.x0, b.y1 - b.y0);  // origin + extent: one unsigned compare per axis
+#if GCP_BOX_MASK
+    {
+      // the box as two 16-bit masks over the tile's columns and rows: membership of a pixel is ONE and + ONE compare
+      // against the lane's own two bits, and a wave knows from the row half alone whether the entry touches it
+      const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
+      const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
+      const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
+      const unsigned rm = (r1 >= r0) ? ((2u << r1) - (1u << r0)) : 0u;
+      s.mask[j] = cm | (rm << 16);
+    }
+#endif
     const float op = a.opacity[g];
     s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], op, op != 0.0f ? 1.0f / op : 0.0f);
     // Λ pre-scaled by -0.5*log2(e): g = exp(-0.5 d Λ d^T) becomes ONE v_exp_f32 of d Λ' d^T.  The extra rounding of
@@ -328,17 +346,25 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   const int px = (tile % a.tiles_x) * kTile + (lane & 15);
   const int py = (tile / a.tiles_x) * kTile + w * 4 + (lane >> 4);
   const float fx = (float)px, fy = (float)py;
+  const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
+  const unsigned wave_rows = 0xfu << (16 + w * 4);
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   for (int base = first; base < last; base += kStage) {
     const int cnt = min(kStage, last - base);
     __syncthreads();
-    stage_entries<kStage>(a, s, base, cnt);
+    stage_entries<kStage>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
     __syncthreads();
     for (int k = 0; k < cnt; ++k) {
+#if GCP_BOX_MASK
+      const unsigned m = __builtin_amdgcn_readfirstlane(s.mask[k]);
+      if ((m & wave_rows) == 0u) continue;  // scalar: the entry's rows miss this wave's four
+      const bool in = (m & lane_bits) == lane_bits;
+#else
       const int4 bx = s.box[k];
       const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) continue;
+#endif
       if (in) {  // (the branch-free form that pays off in the backward is 7 % slower here)
         const float4 ge = s.geo[k];
         const float4 vi = s.vin[k];
@@ -385,16 +411,24 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     g0 = grad_image[o]; g1 = grad_image[o + 1]; g2 = grad_image[o + 2];
     gC = g0 * image[o] + g1 * image[o + 1] + g2 * image[o + 2];  // sum over the pixel's pairs of (g . p)
   }
+  const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
+  const unsigned wave_rows = 0xfu << (16 + w * 4);
   float T = 1.0f, acc = 0.0f;
   for (int base = first; base < last; base += kStageBwd) {
     const int cnt = min(kStageBwd, last - base);
     __syncthreads();
-    stage_entries<kStageBwd>(a, s, base, cnt);
+    stage_entries<kStageBwd>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();
     for (int k = 0; k < cnt; ++k) {
+#if GCP_BOX_MASK
+      const unsigned m = __builtin_amdgcn_readfirstlane(s.mask[k]);
+      const bool in = (m & lane_bits) == lane_bits;
+      if ((m & wave_rows) == 0u) {
+#else
       const int4 bx = s.box[k];
       const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) {
+#endif
         if (lane < 4 * kRowVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
         continue;
       }

@@ -341,7 +341,8 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
 __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __restrict__ image) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStage> s;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id in an SGPR: the row test below is scalar
   const int tile = blockIdx.x;
   const int px = (tile % a.tiles_x) * kTile + (lane & 15);
   const int py = (tile / a.tiles_x) * kTile + w * 4 + (lane >> 4);
@@ -351,19 +352,21 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   for (int base = first; base < last; base += kStage) {
-    const int cnt = min(kStage, last - base);
+    const int cnt = __builtin_amdgcn_readfirstlane(min(kStage, last - base));  // scalar loop bound
     __syncthreads();
     stage_entries<kStage>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
     __syncthreads();
-    for (int k = 0; k < cnt; ++k) {
+    // One list entry.  `in` costs one v_and + one v_cmp against the lane's own two bits; whether the entry touches
+    // this wave at all is decided on the scalar unit from the row half of the mask.
+    auto blend_one = [&](int k) {
 #if GCP_BOX_MASK
       const unsigned m = __builtin_amdgcn_readfirstlane(s.mask[k]);
-      if ((m & wave_rows) == 0u) continue;  // scalar: the entry's rows miss this wave's four
+      if ((m & wave_rows) == 0u) return;
       const bool in = (m & lane_bits) == lane_bits;
 #else
       const int4 bx = s.box[k];
       const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
-      if (__ballot(in) == 0ull) continue;
+      if (__ballot(in) == 0ull) return;
 #endif
       if (in) {  // (the branch-free form that pays off in the backward is 7 % slower here)
         const float4 ge = s.geo[k];
@@ -382,7 +385,14 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
         }
         T = incl;
       }
+    };
+    // unrolled by hand (hipcc declines): with the box test down to 4 VALU the per-entry cost is the scalar unit's —
+    // loop counter, LDS address bumps, compare, branch, one SALU issue slot each
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+      blend_one(k); blend_one(k + 1); blend_one(k + 2); blend_one(k + 3);
     }
+    for (; k < cnt; ++k) blend_one(k);
   }
   if (px <= a.W && py <= a.H) {
     float* o = image + ((i64)py * (a.W + 1) + px) * 3;
@@ -398,7 +408,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
   __shared__ float s_part[kStageBwd][16][kRowVals];  // [entry][pixel row of the tile][value]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id in an SGPR: the row test below is scalar
   const int tile = blockIdx.x;
   const int ttx = tile % a.tiles_x, tty = tile / a.tiles_x;
   const int px = ttx * kTile + (lane & 15);
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   const unsigned wave_rows = 0xfu << (16 + w * 4);
   float T = 1.0f, acc = 0.0f;
   for (int base = first; base < last; base += kStageBwd) {
-    const int cnt = min(kStageBwd, last - base);
+    const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
     __syncthreads();
     stage_entries<kStageBwd>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();

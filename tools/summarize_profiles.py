@@ -45,7 +45,9 @@ def main():
     os.makedirs(out, exist_ok=True)
     stats = max(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(stats)))
-    ours = [r for r in rows if "gcp_" in r["Name"]]
+    # the library's kernels: the scans (gcp_*) and, from bench.py's function_level / caller_level legs, k_* (binning,
+    # blend, sort, projection, loss)
+    ours = [r for r in rows if "gcp_" in r["Name"] or "::k_" in r["Name"]]
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
         w.writeheader()

@@ -122,12 +122,16 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=120)
     ap.add_argument("--iterations", type=int, default=400)
     ap.add_argument("--densify-from", type=int, default=500)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend under torchrun (nccl = RCCL; gloo to rehearse on one GPU)")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:  # python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 examples/train_cameras.py
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(a.backend)
     if a.colmap:
         start, P, K, wh, targets = load_colmap(a.colmap, device)
     else:

@@ -323,3 +323,45 @@ def test_training_from_a_colmap_directory(device, tmp_path):
     assert photos.shape == (n_cam, 3, height, width) and float((photos - targets).abs().max()) <= 0.5 / 255 + 1e-6
     _, losses = train(xyz2, P2, K2, wh2, photos, iterations=60, densify_from_iter=1000, opacity_reset_interval=0, log=lambda *_: None)
     assert np.mean(losses[-5:]) < 0.85 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+
+def test_render_is_invariant_to_gaussian_order_and_transparent_extras(device):
+    """Size-independent properties of projection + depth sort + Function: the picture does not depend on the order the
+    Gaussians are stored in (gradients follow the permutation), fully transparent Gaussians change nothing, and
+    swapping cameras swaps pictures."""
+    n = 4000
+    w = random_world(n, 2, 96, 64, 21, device)
+    names = ("mean", "variance_q", "variance_scale", "opacity", "color")
+    wimg = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(5)).to(device)
+
+    def run(world, cams=(0, 1)):
+        model = make_model(world)
+        idx = torch.tensor(cams, device=device)
+        images = model(world["P"][idx], world["K"][idx], world["wh"][idx], list(cams))[0]
+        (images * wimg[: len(cams)]).sum().backward()
+        return images.detach(), {k: getattr(model, k).grad for k in names}
+
+    base_img, base_grad = run(w)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(6)).to(device)
+    shuffled = dict(w, **{k: w[k][perm].contiguous() for k in names})
+    img, grad = run(shuffled)
+    torch.testing.assert_close(img, base_img, atol=TOL, rtol=TOL)
+    for k in names:
+        scale = base_grad[k].abs().max().item()
+        assert (grad[k] - base_grad[k][perm]).abs().max().item() <= 1e-4 * scale, k
+
+    extra = 500  # opacity logit -inf -> alpha exactly 0: no contribution, zero gradient for everything but nothing breaks
+    g = torch.Generator().manual_seed(7)
+    more = {k: torch.cat([w[k], w[k][torch.randint(0, n, (extra,), generator=g).to(device)]]) for k in names}
+    more["opacity"][n:] = -float("inf")
+    img2, grad2 = run(dict(w, **more))
+    torch.testing.assert_close(img2, base_img, atol=TOL, rtol=TOL)
+    for k in names:
+        assert torch.isfinite(grad2[k]).all(), k
+        scale = base_grad[k].abs().max().item()
+        assert (grad2[k][:n] - base_grad[k]).abs().max().item() <= 1e-4 * scale, k
+    assert float(grad2["color"][n:].abs().max()) == 0.0
+
+    swapped = run(w, cams=(1, 0))[0]
+    torch.testing.assert_close(swapped[0], base_img[1], atol=0, rtol=0)
+    torch.testing.assert_close(swapped[1], base_img[0], atol=0, rtol=0)

@@ -128,7 +128,7 @@ def caller_level(dev, workload):
     """Row f4 (outside the timed region, informational): one training step of the caller — camera projection,
     Function, L1 + D-SSIM loss, backward to the five parameter tensors — on 10^6 Gaussians and one 1920x1080 camera,
     with the fused projection and loss kernels.  (The reference's op-by-op PyTorch formulation of projection and loss,
-    gs_model.py:277-425 / gs_control.py:180-182, around the same Function is timed by tests/bench_reference_gpu.py.)"""
+    gs_model.py:277-425 / gs_control.py:180-182, around the same Function is timed by tests/bench_reference_caller_gpu.py.)"""
     import time
 
     import torch

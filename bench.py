@@ -37,6 +37,7 @@ def cpu_baseline(p, sample_pairs):
     import torch
 
     from oracle import c_oracle as co
+    from oracle import ref as oref
     from oracle import torch_path as tp
 
     inv_len = p.inv_len.cpu()
@@ -68,6 +69,19 @@ def cpu_baseline(p, sample_pairs):
     t5 = time.perf_counter()
     tp.grouped_cumprod(x[:s8].contiguous(), key[:s8].contiguous())
     t6 = time.perf_counter()
+    # the reference's OWN forward (grouped_cumprod_forward.cu, unmodified, rocThrust CPP backend: sequential) where the
+    # build container compiled it into oracle/_ref/
+    ref_fwd = None
+    host = oref.load("grouped_cumprod_ref_host")
+    if host is not None:
+        y_ref = torch.empty_like(x1)
+        host.grouped_cumprod_forward(x1[:1024].contiguous(), k1[:1024].contiguous(), y_ref[:1024])
+        t7 = time.perf_counter()
+        host.grouped_cumprod_forward(x1, k1, y_ref)
+        t8 = time.perf_counter()
+        ref_fwd = {"value": s1 / (t8 - t7), "unit": "pairs/s (forward only)", "cores": 1, "kind": "reference",
+                   "sample": f"{s1} pairs, cuda_kernel/grouped_cumprod_forward.cu compiled for the host (oracle/_ref)",
+                   "equals_port": bool(torch.equal(y_ref, y1))}
     return {
         "value": s / (t2 - t0),
         "unit": "pairs/s",
@@ -79,6 +93,7 @@ def cpu_baseline(p, sample_pairs):
         "single_thread": {"value": s1 / (t4 - t3), "unit": "pairs/s", "cores": 1, "sample": f"{s1} pairs"},
         "torch_cumprod_path_forward": {"value": s8 / (t6 - t5), "unit": "pairs/s", "threads": torch.get_num_threads(),
                                        "sample": f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"},
+        "reference_host_forward": ref_fwd,
     }
 
 

@@ -77,7 +77,7 @@ def test_product_does_not_import_the_oracle():
     # bench.py may use the oracle only inside its cpu_baseline leg
     bench = open(os.path.join(ROOT, "bench.py")).read()
     body = bench[bench.index("def cpu_baseline") : bench.index("def function_level")]
-    assert bench.count("from oracle") == body.count("from oracle") == 2
+    assert bench.count("from oracle") == body.count("from oracle") == 3
 
 
 def test_cpu_tensors_are_rejected():

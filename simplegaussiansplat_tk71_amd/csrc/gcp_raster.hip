@@ -47,6 +47,7 @@ constexpr int kStage = 256;         // list entries staged per LDS round (forwar
 constexpr int kStageBwd = 32;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kGradVals = 9;        // per (tile, Gaussian) slot: go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
 constexpr int kRowVals = 7;         // per pixel row in LDS: go, gl0..2, S(c), S(c dx), S(c dx dx)   (dy is constant along a row)
+constexpr int kRowSlots = 8;        // LDS slots per pixel row (the transposed reduction below leaves 8 values in 8 lane classes)
 constexpr int kScanChunk = 2048;    // ints per prefix-sum block
 
 // sum over each 16-lane DPP row (= one pixel row of the tile); valid in lanes 15, 31, 47, 63
@@ -56,6 +57,14 @@ __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_f<0x114, 0xf>(0.0f, v);
   v += dpp_f<0x118, 0xf>(0.0f, v);
   return v;
+}
+
+// One step of the transposed reduction: lanes with `second` false keep value a, the others keep b; each adds its
+// partner's copy of the value it keeps (partner = DPP pattern CTRL, which must flip the class bit).
+template <int CTRL>
+__device__ __forceinline__ float xchg_sum(bool second, float a, float b) {
+  const float keep = second ? b : a, send = second ? a : b;
+  return keep + dpp_f<CTRL, 0xf>(0.0f, send);
 }
 
 struct TileGrid { int tx, ty; };
@@ -327,6 +336,9 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
   }
 }
 
+#ifndef GCP_DPP_ASM
+#define GCP_DPP_ASM 1
+#endif
 #ifndef GCP_BLEND_FMA
 #define GCP_BLEND_FMA 1
 #endif
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
-  __shared__ float s_part[kStageBwd][16][kRowVals];  // [entry][pixel row of the tile][value]
+  __shared__ float s_part[kStageBwd][16][kRowSlots];  // [entry][pixel row of the tile][value]
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id in an SGPR: the row test below is scalar
   const int tile = blockIdx.x;
@@ -424,6 +436,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   }
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
   const unsigned wave_rows = 0xfu << (16 + w * 4);
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+  float* const row_slot = &s_part[0][w * 4 + (lane >> 4)][(b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
   float T = 1.0f, acc = 0.0f;
   for (int base = first; base < last; base += kStageBwd) {
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
       if (__ballot(in) == 0ull) {
 #endif
-        if (lane < 4 * kRowVals) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
+        if (lane < 4 * kRowSlots) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
         continue;
       }
       // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
@@ -466,15 +480,46 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       float r_cx = r_c * dx;
       float r_xx = r_cx * dx;
       T = in ? incl : T;
-      r_o = row_sum16(r_o);
-      r_l0 = row_sum16(r_l0); r_l1 = row_sum16(r_l1); r_l2 = row_sum16(r_l2);
-      r_c = row_sum16(r_c); r_cx = row_sum16(r_cx); r_xx = row_sum16(r_xx);
-      // keep the last DPP add fused and outside the lane-15 branch (hipcc otherwise sinks it there as
-      // v_mov 0 + v_mov_b32_dpp + v_add)
-      asm volatile("" : "+v"(r_o), "+v"(r_l0), "+v"(r_l1), "+v"(r_l2), "+v"(r_c), "+v"(r_cx), "+v"(r_xx));
-      if ((lane & 15) == 15) {
-        float* d = s_part[k][w * 4 + (lane >> 4)];
-        d[0] = r_o; d[1] = r_l0; d[2] = r_l1; d[3] = r_l2; d[4] = r_c; d[5] = r_cx; d[6] = r_xx;
+      // Seven 16-lane row sums by a transposed butterfly: at each step a lane keeps half of its values and hands the
+      // other half to its partner, so the live registers halve.  Partners: 15-i, 7-i (within each half), i^2, i^1;
+      // afterwards lane i holds the row sum of value ((i>>1)&1)*4 + ((i>>2)&1)*2 + ((i>>3)&1) (slot 7 is a dummy).
+      // The first two steps split the lanes by bit 3 and bit 2, i.e. by DPP bank: two bank-masked v_add_f32_dpp
+      // writing one destination do "keep + partner's copy" for both classes without a select (7 + 4 VALU); the last
+      // two need selects (3 + 1).  15 VALU instead of 7 x 4 = 28.
+      {
+        float q0, q1, q2, q3, p0, p1;
+#if GCP_DPP_ASM
+        // s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"    // lanes 0-7 : go
+            "v_add_f32_dpp %1, %6, %6 row_mirror row_mask:0xf bank_mask:0x3\n\t"    //             gl1
+            "v_add_f32_dpp %2, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"    //             S(c)
+            "v_add_f32_dpp %3, %10, %10 row_mirror row_mask:0xf bank_mask:0xf\n\t"  // all lanes : S(c dx dx)
+            "v_add_f32_dpp %0, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"    // lanes 8-15: gl0
+            "v_add_f32_dpp %1, %7, %7 row_mirror row_mask:0xf bank_mask:0xc\n\t"    //             gl2
+            "v_add_f32_dpp %2, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"    //             S(c dx)
+            : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+            : "v"(r_o), "v"(r_l0), "v"(r_l1), "v"(r_l2), "v"(r_c), "v"(r_cx), "v"(r_xx));
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"  // bit 2 clear: from q0 / q2
+            "v_add_f32_dpp %1, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"  // bit 2 set  : from q1 / q3
+            "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+            : "=&v"(p0), "=&v"(p1)
+            : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+#else
+        q0 = xchg_sum<0x140>(b3, r_o, r_l0);     // b3 = 0 lanes: go     | b3 = 1: gl0
+        q1 = xchg_sum<0x140>(b3, r_l1, r_l2);    //               gl1    |         gl2
+        q2 = xchg_sum<0x140>(b3, r_c, r_cx);     //               S(c)   |         S(c dx)
+        q3 = r_xx + dpp_f<0x140, 0xf>(0.0f, r_xx);  // S(c dx dx) in both classes; the b3 = 1 copy lands in slot 7
+        p0 = xchg_sum<0x141>(b2, q0, q1);
+        p1 = xchg_sum<0x141>(b2, q2, q3);
+#endif
+        const float o0 = xchg_sum<0x4e>(b1, p0, p1);
+        const float tot = o0 + dpp_f<0xb1, 0xf>(0.0f, o0);
+        row_slot[k * (16 * kRowSlots)] = tot;  // lanes i and i^1 store the same word
       }
     }
     __syncthreads();

@@ -293,19 +293,16 @@ struct BlendArgs {
   int W, H, tiles_x;
 };
 
-#ifndef GCP_BOX_MASK
-#define GCP_BOX_MASK 1
-#endif
-
 template <int STAGE>
 struct Staged {
   int4 box[STAGE];     // x0, y0, x1-x0, y1-y0 (clamped to the image)
   float4 geo[STAGE];   // mx, my, opacity, 1/opacity (0 if opacity == 0)
   float4 vin[STAGE];   // a b c d of Λ' = -0.5*log2(e) * Λ  (Λ = [[a,b],[c,d]])
   float4 col[STAGE];   // l0 l1 l2 -
-#if GCP_BOX_MASK
   unsigned mask[STAGE];  // bits 0-15: tile columns inside the box, bits 16-31: tile rows inside the box
-#endif
+  // hits[w][c]: bit j set = staged entry 64*c + j reaches into the four pixel rows of wave w.  A wave walks the set
+  // bits of its own words (scalar s_ff1 / s_andn2) and never sees the entries that miss it.
+  unsigned long long hits[4][(STAGE + 63) / 64];
 };
 
 template <int STAGE>
@@ -314,18 +311,19 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     const i64 g = a.tile_list[first + j];
     Box b;
     load_box(a.start, a.end, g, a.W, a.H, b);
-    s.box[j] = make_int4(b.x0, b.y0, b.x1 - b.x0, b.y1 - b.y0);  // origin + extent: one unsigned compare per axis
-#if GCP_BOX_MASK
-    {
-      // the box as two 16-bit masks over the tile's columns and rows: membership of a pixel is ONE and + ONE compare
-      // against the lane's own two bits, and a wave knows from the row half alone whether the entry touches it
-      const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
-      const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
-      const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
-      const unsigned rm = (r1 >= r0) ? ((2u << r1) - (1u << r0)) : 0u;
-      s.mask[j] = cm | (rm << 16);
+    s.box[j] = make_int4(b.x0, b.y0, b.x1 - b.x0, b.y1 - b.y0);
+    // the box as two 16-bit masks over the tile's columns and rows: membership of a pixel is ONE and + ONE compare
+    // against the lane's own two bits
+    const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
+    const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
+    const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
+    const unsigned rm = (r1 >= r0) ? ((2u << r1) - (1u << r0)) : 0u;
+    s.mask[j] = cm | (rm << 16);
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {  // entries j of one 64-lane staging wave form one word per target wave
+      const unsigned long long touched = __ballot(((rm >> (4 * w2)) & 0xfu) != 0u);
+      if ((threadIdx.x & 63) == 0) s.hits[w2][j >> 6] = touched;
     }
-#endif
     const float op = a.opacity[g];
     s.geo[j] = make_float4(a.mean[2 * g], a.mean[2 * g + 1], op, op != 0.0f ? 1.0f / op : 0.0f);
     // Λ pre-scaled by -0.5*log2(e): g = exp(-0.5 d Λ d^T) becomes ONE v_exp_f32 of d Λ' d^T.  The extra rounding of
@@ -334,6 +332,12 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     s.vin[j] = make_float4(kS * a.vinv[4 * g], kS * a.vinv[4 * g + 1], kS * a.vinv[4 * g + 2], kS * a.vinv[4 * g + 3]);
     s.col[j] = make_float4(a.l_d[3 * g], a.l_d[3 * g + 1], a.l_d[3 * g + 2], 0.0f);
   }
+}
+
+// the set bits of a wave-uniform 64-bit word, lowest first, on the scalar unit
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
 #ifndef GCP_DPP_ASM
@@ -360,7 +364,6 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   const int py = (tile / a.tiles_x) * kTile + w * 4 + (lane >> 4);
   const float fx = (float)px, fy = (float)py;
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
-  const unsigned wave_rows = 0xfu << (16 + w * 4);
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   for (int base = first; base < last; base += kStage) {
@@ -368,43 +371,33 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
     __syncthreads();
     stage_entries<kStage>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
     __syncthreads();
-    // One list entry.  `in` costs one v_and + one v_cmp against the lane's own two bits; whether the entry touches
-    // this wave at all is decided on the scalar unit from the row half of the mask.
-    auto blend_one = [&](int k) {
-#if GCP_BOX_MASK
-      const unsigned m = __builtin_amdgcn_readfirstlane(s.mask[k]);
-      if ((m & wave_rows) == 0u) return;
-      const bool in = (m & lane_bits) == lane_bits;
-#else
-      const int4 bx = s.box[k];
-      const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
-      if (__ballot(in) == 0ull) return;
-#endif
-      if (in) {  // (the branch-free form that pays off in the backward is 7 % slower here)
-        const float4 ge = s.geo[k];
-        const float4 vi = s.vin[k];
-        const float4 co = s.col[k];
-        const float dx = fx - ge.x, dy = fy - ge.y;
-        // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
-        const float t0 = dx * vi.x + dy * vi.z;
-        const float t1 = dx * vi.y + dy * vi.w;
-        const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
-        const float anti = 1.0f - ge.z * g;             // gs_model.py:535
-        const float incl = T * anti;                    // inclusive grouped cumprod
-        if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
-          const float wgt = T * ge.z * g;               // gs_model.py:500
-          c0 += wgt * co.x; c1 += wgt * co.y; c2 += wgt * co.z;
+    // Only the entries whose rows reach this wave (hits[w]), in list order.
+    const int chunks = (cnt + 63) >> 6;
+    for (int c = 0; c < chunks; ++c) {
+      unsigned long long hits = uniform64(s.hits[w][c]);
+      while (hits) {
+        const int k = c * 64 + __builtin_ctzll(hits);
+        hits &= hits - 1;
+        const unsigned m = s.mask[k];
+        if ((m & lane_bits) == lane_bits) {  // (the branch-free form that pays off in the backward is 7 % slower here)
+          const float4 ge = s.geo[k];
+          const float4 vi = s.vin[k];
+          const float4 co = s.col[k];
+          const float dx = fx - ge.x, dy = fy - ge.y;
+          // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
+          const float t0 = dx * vi.x + dy * vi.z;
+          const float t1 = dx * vi.y + dy * vi.w;
+          const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
+          const float anti = 1.0f - ge.z * g;             // gs_model.py:535
+          const float incl = T * anti;                    // inclusive grouped cumprod
+          if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
+            const float wgt = T * ge.z * g;               // gs_model.py:500
+            c0 += wgt * co.x; c1 += wgt * co.y; c2 += wgt * co.z;
+          }
+          T = incl;
         }
-        T = incl;
       }
-    };
-    // unrolled by hand (hipcc declines): with the box test down to 4 VALU the per-entry cost is the scalar unit's —
-    // loop counter, LDS address bumps, compare, branch, one SALU issue slot each
-    int k = 0;
-    for (; k + 4 <= cnt; k += 4) {
-      blend_one(k); blend_one(k + 1); blend_one(k + 2); blend_one(k + 3);
     }
-    for (; k < cnt; ++k) blend_one(k);
   }
   if (px <= a.W && py <= a.H) {
     float* o = image + ((i64)py * (a.W + 1) + px) * 3;
@@ -435,7 +428,6 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     gC = g0 * image[o] + g1 * image[o + 1] + g2 * image[o + 2];  // sum over the pixel's pairs of (g . p)
   }
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
-  const unsigned wave_rows = 0xfu << (16 + w * 4);
   const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
   float* const row_slot = &s_part[0][w * 4 + (lane >> 4)][(b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
   float T = 1.0f, acc = 0.0f;
@@ -444,19 +436,14 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     __syncthreads();
     stage_entries<kStageBwd>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();
-    for (int k = 0; k < cnt; ++k) {
-#if GCP_BOX_MASK
-      const unsigned m = __builtin_amdgcn_readfirstlane(s.mask[k]);
+    // only the entries whose rows reach this wave, in list order (the finalize below skips this wave's rows for the
+    // others, so nothing needs zeroing)
+    unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s.hits[w][0]);
+    while (hits) {
+      const int k = __builtin_ctz(hits);
+      hits &= hits - 1;
+      const unsigned m = s.mask[k];
       const bool in = (m & lane_bits) == lane_bits;
-      if ((m & wave_rows) == 0u) {
-#else
-      const int4 bx = s.box[k];
-      const bool in = ((unsigned)(px - bx.x) <= (unsigned)bx.z) & ((unsigned)(py - bx.y) <= (unsigned)bx.w);
-      if (__ballot(in) == 0ull) {
-#endif
-        if (lane < 4 * kRowSlots) (&s_part[k][w * 4][0])[lane] = 0.0f;  // this wave's 4 pixel rows
-        continue;
-      }
       // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
       const float4 ge = s.geo[k];
       const float4 vi = s.vin[k];
@@ -533,12 +520,16 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const float my = s.geo[j].y;
       float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f, cx = 0.0f, cy = 0.0f, xx = 0.0f, xy = 0.0f, yy = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* d = s_part[j][r];
-        const float dy = (float)(tty * kTile + r) - my;  // constant along the pixel row
-        o0 += d[0]; o1 += d[1]; o2 += d[2]; o3 += d[3];
-        cx += d[5]; cy += dy * d[4];
-        xx += d[6]; xy += dy * d[5]; yy += dy * dy * d[4];
+      for (int wv = 0; wv < 4; ++wv) {
+        if (!(((unsigned)s.hits[wv][0] >> j) & 1u)) continue;  // that wave never wrote its rows for this entry
+#pragma unroll
+        for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
+          const float* d = s_part[j][r];
+          const float dy = (float)(tty * kTile + r) - my;  // constant along the pixel row
+          o0 += d[0]; o1 += d[1]; o2 += d[2]; o3 += d[3];
+          cx += d[5]; cy += dy * d[4];
+          xx += d[6]; xy += dy * d[5]; yy += dy * dy * d[4];
+        }
       }
       out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = cx; out[5] = cy; out[6] = xx; out[7] = xy; out[8] = yy;
     }

@@ -42,9 +42,15 @@
 namespace {
 using namespace gcp;
 
+#ifndef GCP_STAGE_BWD
+#define GCP_STAGE_BWD 32
+#endif
+#ifndef GCP_HITS64
+#define GCP_HITS64 (GCP_STAGE_BWD > 32)
+#endif
 constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
-constexpr int kStageBwd = 32;       // (backward; LDS also holds the per-pixel-row partial sums)
+constexpr int kStageBwd = GCP_STAGE_BWD;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kGradVals = 9;        // per (tile, Gaussian) slot: go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
 constexpr int kRowVals = 7;         // per pixel row in LDS: go, gl0..2, S(c), S(c dx), S(c dx dx)   (dy is constant along a row)
 constexpr int kRowSlots = 8;        // LDS slots per pixel row (the transposed reduction below leaves 8 values in 8 lane classes)
@@ -438,10 +444,18 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     __syncthreads();
     // only the entries whose rows reach this wave, in list order (the finalize below skips this wave's rows for the
     // others, so nothing needs zeroing)
+#if GCP_HITS64
+    unsigned long long hits = uniform64(s.hits[w][0]);
+    while (hits) {
+      const int k = __builtin_ctzll(hits);
+      hits &= hits - 1;
+#else
+    static_assert(kStageBwd <= 32, "one 32-bit word of hits per wave");
     unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s.hits[w][0]);
     while (hits) {
       const int k = __builtin_ctz(hits);
       hits &= hits - 1;
+#endif
       const unsigned m = s.mask[k];
       const bool in = (m & lane_bits) == lane_bits;
       // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
@@ -521,7 +535,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f, cx = 0.0f, cy = 0.0f, xx = 0.0f, xy = 0.0f, yy = 0.0f;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) {
-        if (!(((unsigned)s.hits[wv][0] >> j) & 1u)) continue;  // that wave never wrote its rows for this entry
+        if (!((s.hits[wv][0] >> j) & 1ull)) continue;  // that wave never wrote its rows for this entry
 #pragma unroll
         for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
           const float* d = s_part[j][r];

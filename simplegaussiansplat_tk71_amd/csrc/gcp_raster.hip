@@ -467,17 +467,18 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const float t1 = dx * vi.y + dy * vi.w;
       const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
       const float op = ge.z;
-      const float anti = 1.0f - op * g;
+      const float og = op * g;
+      const float anti = 1.0f - op * g;                  // one fma, as in the forward: both traversals see the same T
       const float incl = T * anti;
       const bool keep = in & (incl != 0.0f);
-      const float wgt = keep ? T * op * g : 0.0f;
-      const float gp = g0 * (wgt * co.x) + g1 * (wgt * co.y) + g2 * (wgt * co.z);  // gs_model.py:632
+      const float wgt = keep ? T * og : 0.0f;
+      const float gp = wgt * (g0 * co.x + g1 * co.y + g2 * co.z);  // sum_c g_c p_c with p = wgt * l (gs_model.py:632)
       acc += gp;
       const float S = gC - acc;                          // exclusive suffix sum of gp (gs_model.py:716-722)
       const float sa = S * __builtin_amdgcn_rcpf(anti);   // S / anti (v_rcp_f32, 1 ulp)
       float r_o = keep ? gp * ge.w - g * sa : 0.0f;       // gs_model.py:733-740 (gp / o for o != 0)
       float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;  // true dL/dl (reference: gp / l, Q2)
-      float r_c = keep ? gp - (op * g) * sa : 0.0f;       // gs_model.py:747-748, :757-758
+      float r_c = keep ? gp - og * sa : 0.0f;       // gs_model.py:747-748, :757-758
       float r_cx = r_c * dx;
       float r_xx = r_cx * dx;
       T = in ? incl : T;

@@ -295,6 +295,15 @@ int gcp_ssim_l1_backward(const float* img1, const float* img2, const float* dm_d
                          int64_t planes, int32_t height, int32_t width, const float* window11_host, const float* scales,
                          float* grad_img1, void* stream);
 
+/* ---- the caller's optimiser step ---------------------------------------------------------
+ * torch.optim.Adam's update (no weight decay, no amsgrad; gs_model.py:43-47, :64-67) of one parameter tensor of n
+ * floats, in place: exp_avg = beta1 exp_avg + (1 - beta1) grad; exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2;
+ * param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).  step counts from 1.
+ * Hyper-parameters are doubles (1 - beta and the bias corrections are formed in double, as torch does, then rounded
+ * once).  All four arrays 16-byte aligned. */
+int gcp_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

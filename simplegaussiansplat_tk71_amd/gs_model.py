@@ -35,6 +35,7 @@ from .cuda_kernel import custom_autograd_grouped_cumprod
 __all__ = [
     "GS_dataset",
     "GS_model_with_param",
+    "HipAdam",
     "camera_inputs",
     "qvec_to_rotmat_batch",
     "get_expon_lr_func",
@@ -162,6 +163,44 @@ def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, ti
     return cams, grad_iter, (width, height)
 
 
+class HipAdam:
+    """torch.optim.Adam's update (default betas / eps, no weight decay, no amsgrad — what the reference constructs at
+    gs_model.py:43-47) on the HIP library: one streaming kernel per parameter tensor (csrc/gcp_optim.hip, gcp_adam_step)
+    instead of torch's multi-tensor launches (0.38 -> 0.2 ms per step at 10^6 Gaussians).  Same interface as far as the
+    model uses it: `param_groups` with one tensor and an `lr` each, `step()`, `zero_grad()`."""
+
+    def __init__(self, param_groups, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = [dict(g, params=list(g["params"]) if isinstance(g["params"], (list, tuple)) else [g["params"]])
+                             for g in param_groups]
+        self.betas, self.eps = betas, eps
+        self.state = {}
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("HipAdam updates contiguous float32 GPU tensors")
+                st = self.state.setdefault(p, {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)})
+                st["step"] += 1
+                grad = p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    _lib.check(lib.gcp_adam_step(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                                 p.numel(), float(group["lr"]), self.betas[0], self.betas[1], self.eps, st["step"],
+                                                 torch.cuda.current_stream(p.device).cuda_stream), "gcp_adam_step")
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+
 class GS_dataset(torch.utils.data.Dataset):
     """Cameras and their image names (reference: gs_model.py:13-30)."""
 
@@ -218,8 +257,9 @@ class GS_model_with_param(torch.nn.Module):
     # ---- optimiser plumbing (reference: gs_model.py:43-67) -------------------------------------------------
     def changing_optimizer(self):
         groups = [{"params": p, "lr": float(self.lr[name])} for name, p in self.named_parameters(recurse=False)]
-        # one multi-tensor kernel per step on the GPU instead of ~30 element-wise ones (0.95 -> 0.25 ms at 10^6 Gaussians)
-        self._optimizer = torch.optim.Adam(groups, fused=True) if self.mean.is_cuda else torch.optim.Adam(groups)
+        # on the GPU one streaming kernel per tensor (torch's per-op Adam: 0.95 ms per step at 10^6 Gaussians, its fused
+        # multi-tensor form 0.38, HipAdam 0.2)
+        self._optimizer = HipAdam(groups) if self.mean.is_cuda else torch.optim.Adam(groups)
 
     def set_mean_lr(self, iteration):
         """The reference rebuilds Adam (and drops its moments) every step to change one rate (gs_control.py:195-197);

@@ -365,3 +365,32 @@ def test_render_is_invariant_to_gaussian_order_and_transparent_extras(device):
     swapped = run(w, cams=(1, 0))[0]
     torch.testing.assert_close(swapped[0], base_img[1], atol=0, rtol=0)
     torch.testing.assert_close(swapped[1], base_img[0], atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("n", [1, 3, 1001, 3 * 4096 + 2])
+def test_hip_adam_equals_torch_adam(n, device):
+    """gcp_adam_step against torch.optim.Adam (the optimiser the reference builds, gs_model.py:43-47): ten steps with
+    changing gradients and a learning-rate change in between, parameters and both moments."""
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g).to(device)
+    a, b = p0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+    ours, theirs = gm.HipAdam([{"params": a, "lr": 0.01}]), torch.optim.Adam([{"params": b, "lr": 0.01}])
+    for it in range(10):
+        grad = (torch.randn(n, generator=g) * (10.0 ** torch.randint(-3, 2, (1,), generator=g).item())).to(device)
+        a.grad, b.grad = grad.clone(), grad.clone()
+        if it == 5:
+            ours.param_groups[0]["lr"] = theirs.param_groups[0]["lr"] = 0.002
+        ours.step()
+        theirs.step()
+        ours.zero_grad()
+        theirs.zero_grad(set_to_none=True)
+        assert a.grad is None
+    # fp32 round-off only (torch forms the first moment with lerp, m + (g - m)(1 - b1), and divides where this
+    # multiplies): a few ulp of the largest magnitude in each tensor
+    for got, want in ((a.detach(), b.detach()), (ours.state[a]["exp_avg"], theirs.state[b]["exp_avg"]),
+                      (ours.state[a]["exp_avg_sq"], theirs.state[b]["exp_avg_sq"])):
+        assert (got - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1e-30)
+    with pytest.raises(RuntimeError):
+        cpu = torch.zeros(4, requires_grad=True)
+        cpu.grad = torch.ones(4)
+        gm.HipAdam([{"params": cpu, "lr": 0.1}]).step()

@@ -303,14 +303,14 @@ template <int STAGE>
 struct Staged {
   int4 box[STAGE];     // x0, y0, x1-x0, y1-y0 (clamped to the image)
   float4 geo[STAGE];   // mx, my, opacity, box mask as bits (0-15: tile columns inside the box, 16-31: tile rows)
-  float4 vin[STAGE];   // a b c d of Λ' = -0.5*log2(e) * Λ  (Λ = [[a,b],[c,d]])
+  float4 vin[STAGE];   // Λ' = -0.5*log2(e) * Λ, Λ = [[a,b],[c,d]]: a b c d (forward) or a, b + c, d, - (backward)
   float4 col[STAGE];   // l0 l1 l2, 1/opacity (0 if opacity == 0)
   // hits[w][c]: bit j set = staged entry 64*c + j reaches into the four pixel rows of wave w.  A wave walks the set
   // bits of its own words (scalar s_ff1 / s_andn2) and never sees the entries that miss it.
   unsigned long long hits[4][(STAGE + 63) / 64];
 };
 
-template <int STAGE>
+template <int STAGE, bool QUAD3>
 __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>& s, int first, int cnt, int tile_x0, int tile_y0) {
   for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
     const i64 g = a.tile_list[first + j];
@@ -333,7 +333,10 @@ __device__ __forceinline__ void stage_entries(const BlendArgs& a, Staged<STAGE>&
     // Λ pre-scaled by -0.5*log2(e): g = exp(-0.5 d Λ d^T) becomes ONE v_exp_f32 of d Λ' d^T.  The extra rounding of
     // Λ' moves g by < 1e-7 absolute (relative 6e-8*|log2 g|, and g decays as fast as that factor grows).
     constexpr float kS = -0.5f * 1.44269504088896341f;
-    s.vin[j] = make_float4(kS * a.vinv[4 * g], kS * a.vinv[4 * g + 1], kS * a.vinv[4 * g + 2], kS * a.vinv[4 * g + 3]);
+    // QUAD3 (backward): a, b + c, d — the quadratic form in five VALU instead of six; the forward keeps a, b, c, d and the
+    // association of the reference's two matmuls: its per-entry chain is latency-bound and the shorter form is 6 % slower there
+    s.vin[j] = QUAD3 ? make_float4(kS * a.vinv[4 * g], kS * a.vinv[4 * g + 1] + kS * a.vinv[4 * g + 2], kS * a.vinv[4 * g + 3], 0.0f)
+                     : make_float4(kS * a.vinv[4 * g], kS * a.vinv[4 * g + 1], kS * a.vinv[4 * g + 2], kS * a.vinv[4 * g + 3]);
     s.col[j] = make_float4(a.l_d[3 * g], a.l_d[3 * g + 1], a.l_d[3 * g + 2], op != 0.0f ? 1.0f / op : 0.0f);
   }
 }
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   for (int base = first; base < last; base += kStage) {
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStage, last - base));  // scalar loop bound
     __syncthreads();
-    stage_entries<kStage>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
+    stage_entries<kStage, false>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
     __syncthreads();
     // Only the entries whose rows reach this wave (hits[w]), in list order.
     const int chunks = (cnt + 63) >> 6;
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   for (int base = first; base < last; base += kStageBwd) {
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
     __syncthreads();
-    stage_entries<kStageBwd>(a, s, base, cnt, ttx * kTile, tty * kTile);
+    stage_entries<kStageBwd, true>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();
     // only the entries whose rows reach this wave, in list order (the finalize below skips this wave's rows for the
     // others, so nothing needs zeroing)
@@ -459,9 +462,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const float4 co = s.col[k];
       const bool in = (__float_as_uint(ge.w) & lane_bits) == lane_bits;
       const float dx = fx - ge.x, dy = fy - ge.y;
-      const float t0 = dx * vi.x + dy * vi.z;
-      const float t1 = dx * vi.y + dy * vi.w;
-      const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
+      // (d Λ) d^T (gs_model.py:495) as a dx^2 + (b + c) dx dy + d dy^2
+      const float g = __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy);
       const float op = ge.z;
       const float og = op * g;
       const float anti = 1.0f - op * g;                  // one fma, as in the forward: both traversals see the same T

@@ -347,6 +347,9 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
          (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+#ifndef GCP_FWD_EARLY_LOADS
+#define GCP_FWD_EARLY_LOADS 1
+#endif
 #ifndef GCP_DPP_ASM
 #define GCP_DPP_ASM 1
 #endif
@@ -386,9 +389,16 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
         const int k = c * 64 + __builtin_ctzll(hits);
         hits &= hits - 1;
         const float4 ge = s.geo[k];
+#if GCP_FWD_EARLY_LOADS
+        const float4 vi = s.vin[k];  // every listed entry reaches this wave: all three LDS reads in one round trip
+        const float4 co = s.col[k];
+        asm volatile("" :: "v"(vi.x), "v"(co.x));  // keep them ahead of the branch
+        if ((__float_as_uint(ge.w) & lane_bits) == lane_bits) {  // (the branch-free form of the backward is 4 % slower here)
+#else
         if ((__float_as_uint(ge.w) & lane_bits) == lane_bits) {  // (the branch-free form of the backward is 4 % slower here)
           const float4 vi = s.vin[k];
           const float4 co = s.col[k];
+#endif
           const float dx = fx - ge.x, dy = fy - ge.y;
           // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
           const float t0 = dx * vi.x + dy * vi.z;

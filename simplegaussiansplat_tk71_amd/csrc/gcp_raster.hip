@@ -428,7 +428,13 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
-  __shared__ float s_part[kStageBwd][16][kRowSlots];  // [entry][pixel row of the tile][value]
+  // [entry][pixel row of the tile * kRowSlots + value]; one word of padding per entry: the fold below reads with one
+  // thread per entry, and a stride of 128 words would put all of them on one LDS bank
+#ifndef GCP_PART_PAD
+#define GCP_PART_PAD 1
+#endif
+  constexpr int kPartStride = 16 * kRowSlots + GCP_PART_PAD;
+  __shared__ float s_part[kStageBwd][kPartStride];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave id in an SGPR: the row test below is scalar
   const int tile = blockIdx.x;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   }
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
   const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-  float* const row_slot = &s_part[0][w * 4 + (lane >> 4)][(b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
+  float* const row_slot = &s_part[0][(w * 4 + (lane >> 4)) * kRowSlots + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
   float T = 1.0f, acc = 0.0f;
   for (int base = first; base < last; base += kStageBwd) {
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
 #endif
         const float o0 = xchg_sum<0x4e>(b1, p0, p1);
         const float tot = o0 + dpp_f<0xb1, 0xf>(0.0f, o0);
-        row_slot[k * (16 * kRowSlots)] = tot;  // lanes i and i^1 store the same word
+        row_slot[k * kPartStride] = tot;  // lanes i and i^1 store the same word
       }
     }
     __syncthreads();
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         if (!((s.hits[wv][0] >> j) & 1ull)) continue;  // that wave never wrote its rows for this entry
 #pragma unroll
         for (int r = 4 * wv; r < 4 * wv + 4; ++r) {
-          const float* d = s_part[j][r];
+          const float* d = &s_part[j][r * kRowSlots];
           const float dy = (float)(tty * kTile + r) - my;  // constant along the pixel row
           o0 += d[0]; o1 += d[1]; o2 += d[2]; o3 += d[3];
           cx += d[5]; cy += dy * d[4];

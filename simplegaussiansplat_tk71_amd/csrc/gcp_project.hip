@@ -129,6 +129,39 @@ __device__ __forceinline__ void project_one(const Camera& cam, const float* __re
   for (int k = 0; k < 3; ++k) o.view[k] = -o.t[k] / o.tlen;
 }
 
+// The parameter rows of a block's 256 consecutive Gaussians, copied into LDS with contiguous 16-byte loads: read
+// straight from global memory they are 37 four-byte loads per thread, 12-108 bytes apart between neighbouring lanes.
+// Layout: mean [256][3] | quaternion [256][4] | log scale [256][3] | SH [256][3 n_basis].
+struct ParamTile {
+  float *mean, *q, *ls, *sh;
+};
+
+__device__ __forceinline__ ParamTile param_tile(float* base, int n_basis) {
+  ParamTile t;
+  t.mean = base;
+  t.q = t.mean + 3 * kThreads;
+  t.ls = t.q + 4 * kThreads;
+  t.sh = t.ls + 3 * kThreads;
+  (void)n_basis;
+  return t;
+}
+
+__device__ __forceinline__ void copy_rows(float* __restrict__ dst, const float* __restrict__ src, i64 first_word, int words) {
+  // first_word is a multiple of 4 (256 rows per block), so the run starts 16-byte aligned
+  const float4* s4 = reinterpret_cast<const float4*>(src + first_word);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int j = threadIdx.x; j < (words >> 2); j += kThreads) d4[j] = s4[j];
+  for (int j = (words & ~3) + threadIdx.x; j < words; j += kThreads) dst[j] = src[first_word + j];
+}
+
+__device__ __forceinline__ void load_param_tile(const ParamTile& t, const float* mean, const float* q, const float* log_scale,
+                                                const float* color, i64 base, int cnt, int n_basis) {
+  copy_rows(t.mean, mean, 3 * base, 3 * cnt);
+  copy_rows(t.q, q, 4 * base, 4 * cnt);
+  copy_rows(t.ls, log_scale, 3 * base, 3 * cnt);
+  copy_rows(t.sh, color, 3 * (i64)n_basis * base, 3 * n_basis * cnt);
+}
+
 // 3 sqrt(V^2 |lambda|) of the symmetric matrix read from the lower triangle (gs_model.py:327-332)
 __device__ __forceinline__ void box_halfsize(float a, float b, float c, float& hx, float& hy) {
   const float m = 0.5f * (a + c), d = 0.5f * (a - c);
@@ -155,10 +188,18 @@ __global__ __launch_bounds__(kThreads) void k_project_fwd(
     const float* __restrict__ opacity, const float* __restrict__ color, const float* __restrict__ cam_P,
     const float* __restrict__ cam_K, i64 n, int sh_degree, int n_basis, int width, int height, float box_clamp,
     float4* __restrict__ record, int* __restrict__ sort_key, uint8_t* __restrict__ keep, int* __restrict__ row_of) {
+  extern __shared__ float s_stage[];
+  const ParamTile tile = param_tile(s_stage, n_basis);
   const Camera cam = load_camera(cam_P, cam_K);
-  for (i64 i = (i64)blockIdx.x * kThreads + threadIdx.x; i < n; i += (i64)gridDim.x * kThreads) {
+  for (i64 base = (i64)blockIdx.x * kThreads; base < n; base += (i64)gridDim.x * kThreads) {
+    const int cnt = (int)min((i64)kThreads, n - base);
+    __syncthreads();  // the previous chunk's rows are no longer read
+    load_param_tile(tile, mean, q, log_scale, color, base, cnt, n_basis);
+    __syncthreads();
+    const i64 i = base + threadIdx.x;
+    if (i >= n) continue;
     Projected p;
-    project_one(cam, mean, q, log_scale, i, p);
+    project_one(cam, tile.mean, tile.q, tile.ls, threadIdx.x, p);
     float hx, hy;
     box_halfsize(p.a, p.c, p.d, hx, hy);
     const float ilim = 2147483647.f / 1000.f;
@@ -172,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_project_fwd(
     // kept depths are positive floats: their bit patterns sort like the values; culled Gaussians sort last
     sort_key[i] = k ? __float_as_int(p.t[2]) : 0x7fffffff;
     // real spherical harmonics, degree <= 2 (the build's eval_sh; the reference's sh_utility is absent)
-    const float* sh = color + (i64)i * n_basis * 3;
+    const float* sh = tile.sh + threadIdx.x * n_basis * 3;
     const float x = p.view[0], y = p.view[1], z = p.view[2];
     float l[3];
 #pragma unroll
@@ -230,8 +271,8 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
     const float* __restrict__ g_vinv, const float* __restrict__ g_alpha, const float* __restrict__ g_ld,
     float* __restrict__ grad_mean, float* __restrict__ grad_q, float* __restrict__ grad_log_scale,
     float* __restrict__ grad_opacity, float* __restrict__ grad_color) {
-  // gradient rows of the block's 256 Gaussians are staged in LDS and written out as contiguous runs: written straight
-  // from registers they are 38 four-byte stores per thread, 12-108 bytes apart (365 us per 10^6 Gaussians; staged: 140)
+  // parameter rows come in and gradient rows go out through LDS as contiguous runs: straight from / to registers they are
+  // 37 + 38 four-byte accesses per thread, 12-108 bytes apart (gradient rows direct: 365 us per 10^6 Gaussians; staged: 140)
   extern __shared__ float s_stage[];
   float* s_mean = s_stage;
   float* s_q = s_mean + 3 * kThreads;
@@ -243,7 +284,11 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
   float* lls = s_ls + 3 * threadIdx.x;
   float* gsh = s_sh + sh_words * threadIdx.x;
   const Camera cam = load_camera(cam_P, cam_K);
+  const ParamTile tile = param_tile(s_stage, n_basis);  // same layout as the gradient rows: a thread's parameter row is
+                                                         // replaced, in place and by that thread alone, with its gradient row
   for (i64 base = (i64)blockIdx.x * kThreads; base < n; base += (i64)gridDim.x * kThreads) {
+    load_param_tile(tile, mean, q, log_scale, color, base, (int)min((i64)kThreads, n - base), n_basis);
+    __syncthreads();
     const i64 i = base + threadIdx.x;
     const i64 r = i < n ? row_of[i] : -1;
     if (r < 0) {
@@ -255,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
       if (i < n) grad_opacity[i] = 0.f;
     } else {
     Projected p;
-    project_one(cam, mean, q, log_scale, i, p);
+    project_one(cam, tile.mean, tile.q, tile.ls, threadIdx.x, p);  // reads this thread's row before anything overwrites it
 
     // opacity = sigmoid(o)
     const float al = 1.f / (1.f + expf(-opacity[i]));
@@ -266,23 +311,26 @@ __global__ __launch_bounds__(kThreads) void k_project_bwd(
     float Bk[9] = {kShC0, -kShC1 * y, kShC1 * z, -kShC1 * x, kShC2[0] * x * y, kShC2[1] * y * z,
                    kShC2[2] * (2.f * z * z - x * x - y * y), kShC2[3] * x * z, kShC2[4] * (x * x - y * y)};
     const int nb = (sh_degree + 1) * (sh_degree + 1);
-    const float* sh = color + (i64)i * n_basis * 3;
     float gv[3] = {0.f, 0.f, 0.f};  // dL/dview
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
       const float g = g_ld[3 * r + ch];
+      // this channel's coefficients first: the gradient row goes into the very words they are read from
+      float c[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) c[k] = k < nb ? gsh[3 * k + ch] : 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k)
         if (k < n_basis) gsh[3 * k + ch] = k < nb ? g * Bk[k] : 0.f;
       for (int k = 9; k < n_basis; ++k) gsh[3 * k + ch] = 0.f;
       if (sh_degree > 0) {
-        gv[0] += g * (-kShC1 * sh[9 + ch]);
-        gv[1] += g * (-kShC1 * sh[3 + ch]);
-        gv[2] += g * (kShC1 * sh[6 + ch]);
+        gv[0] += g * (-kShC1 * c[3]);
+        gv[1] += g * (-kShC1 * c[1]);
+        gv[2] += g * (kShC1 * c[2]);
         if (sh_degree > 1) {
-          gv[0] += g * (kShC2[0] * y * sh[12 + ch] - 2.f * kShC2[2] * x * sh[18 + ch] + kShC2[3] * z * sh[21 + ch] + 2.f * kShC2[4] * x * sh[24 + ch]);
-          gv[1] += g * (kShC2[0] * x * sh[12 + ch] + kShC2[1] * z * sh[15 + ch] - 2.f * kShC2[2] * y * sh[18 + ch] - 2.f * kShC2[4] * y * sh[24 + ch]);
-          gv[2] += g * (kShC2[1] * y * sh[15 + ch] + 4.f * kShC2[2] * z * sh[18 + ch] + kShC2[3] * x * sh[21 + ch]);
+          gv[0] += g * (kShC2[0] * y * c[4] - 2.f * kShC2[2] * x * c[6] + kShC2[3] * z * c[7] + 2.f * kShC2[4] * x * c[8]);
+          gv[1] += g * (kShC2[0] * x * c[4] + kShC2[1] * z * c[5] - 2.f * kShC2[2] * y * c[6] - 2.f * kShC2[4] * y * c[8]);
+          gv[2] += g * (kShC2[1] * y * c[5] + 4.f * kShC2[2] * z * c[6] + kShC2[3] * x * c[7]);
         }
       }
     }
@@ -413,7 +461,9 @@ int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* 
   if (!mean || !quat_xyzw || !log_scale || !opacity_logit || !sh_coeff || !cam_P || !cam_K || !record || !sort_key || !keep ||
       !row_of || ((uintptr_t)record & 15))
     return GCP_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_project_fwd, dim3(grid_for(n_gauss)), dim3(kThreads), 0, (hipStream_t)stream, mean, quat_xyzw, log_scale,
+  const size_t lds_fwd = (size_t)kThreads * (10 + 3 * (size_t)n_basis) * sizeof(float);
+  if (lds_fwd > 64 * 1024) return GCP_ERR_INVALID_ARGUMENT;  // n_basis <= 18
+  hipLaunchKernelGGL(k_project_fwd, dim3(grid_for(n_gauss)), dim3(kThreads), lds_fwd, (hipStream_t)stream, mean, quat_xyzw, log_scale,
                      opacity_logit, sh_coeff, cam_P, cam_K, (i64)n_gauss, (int)sh_degree, (int)n_basis, (int)width, (int)height,
                      box_clamp, (float4*)record, sort_key, keep, row_of);
   GCP_HIP(hipGetLastError());

@@ -181,7 +181,7 @@ def caller_level(dev, workload):
         "visible": int(cams[0]["boxsize"].numel()),
         "pairs": pairs,
         "step_ms": fused_ms,
-        "reference_formulation_ms": "180 (projection and loss as PyTorch ops around the same Function; tests/bench_reference_caller_gpu.py)",
+        "reference_formulation_ms": "179 (projection and loss as PyTorch ops around the same Function; tests/bench_reference_caller_gpu.py)",
         "pairs_per_s": pairs / (fused_ms * 1e-3),
     }
 

@@ -77,11 +77,18 @@ def mean_neighbour_distance(n, cloud, batch_size=2000):
     return out.repeat(1, 3)
 
 
-def _box_clamp(wh, tile_max_width, dev):
-    """Upper bound of the 3-sigma half extents: 10 * sqrt(W*H) * sigmoid(tile_max_width) (gs_model.py:364-365)."""
-    tile_max = torch.sqrt((wh[0, 0] * wh[0, 1]).to(torch.int32).to(torch.float32)) * torch.sigmoid(
-        torch.as_tensor(tile_max_width, dtype=torch.float32, device=dev))
-    return (tile_max * 10).item()
+_CLAMP_CACHE = {}
+
+
+def _box_clamp(width, height, tile_max_width):
+    """Upper bound of the 3-sigma half extents: 10 * sqrt(W*H) * sigmoid(tile_max_width) in float32, as the reference forms
+    it (gs_model.py:364-365).  Evaluated once per (W, H, setting) on the host: no device work, no read-back."""
+    key = (width, height, float(tile_max_width))
+    if key not in _CLAMP_CACHE:
+        t = torch.sqrt(torch.tensor(width * height, dtype=torch.int32).to(torch.float32)) * torch.sigmoid(
+            torch.tensor(float(tile_max_width), dtype=torch.float32))
+        _CLAMP_CACHE[key] = (t * 10).item()
+    return _CLAMP_CACHE[key]
 
 
 class _ProjectCamera(torch.autograd.Function):
@@ -148,18 +155,19 @@ def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, ti
 
     One HIP kernel per camera and direction (csrc/gcp_project.hip); GPU tensors only — there is no CPU path.  The
     reference's op-by-op PyTorch formulation lives in oracle/gs_forward_torch.py as the checker."""
-    dev = mean.device
-    width, height = wh[0, 0].to(torch.int32), wh[0, 1].to(torch.int32)
-    clamp = _box_clamp(wh, tile_max_width, dev)
-    grad_iter = torch.zeros(mean.shape[0], device=dev, dtype=torch.bool)
+    width, height = (int(v) for v in wh[0].tolist())  # the one device->host read of the image size (.to(int32) truncates, :279)
+    clamp = _box_clamp(width, height, tile_max_width)
+    grad_iter = None
     cams = []
     for c in range(P.shape[0]):
         vinv, alpha, l_d, start, end, mean_xy, boxsize, index, keep = _ProjectCamera.apply(
-            mean, variance_q, variance_scale, opacity, color, P[c], K[c], int(width), int(height), clamp, L_max)
-        grad_iter |= keep
+            mean, variance_q, variance_scale, opacity, color, P[c], K[c], width, height, clamp, L_max)
+        grad_iter = keep if grad_iter is None else grad_iter | keep
         cams.append(None if index.numel() == 0 else {
             "boxsize": boxsize, "startpoint": start, "endpoint": end, "mean": mean_xy, "variance_inverse": vinv,
             "opacity": alpha, "l_d": l_d, "index": index})
+    if grad_iter is None:
+        grad_iter = torch.zeros(mean.shape[0], device=mean.device, dtype=torch.bool)
     return cams, grad_iter, (width, height)
 
 

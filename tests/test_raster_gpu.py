@@ -55,9 +55,11 @@ def test_function_vs_reference_golden(device, name):
 
 
 @pytest.mark.parametrize("n_gauss,w,h,mh,seed,one", [(1, 8, 8, 2, 1, 0), (40, 33, 17, 4, 2, 0), (400, 100, 70, 9, 3, 0),
-                                                      (300, 64, 64, 20, 4, 0), (250, 50, 40, 6, 5, 7), (2500, 255, 191, 10, 6, 0)])
+                                                      (300, 64, 64, 20, 4, 0), (250, 50, 40, 6, 5, 7), (2500, 255, 191, 10, 6, 0),
+                                                      (900, 48, 40, 24, 8, 0)])  # ~800 entries per tile: several staging rounds
 def test_function_vs_dense_oracle(device, n_gauss, w, h, mh, seed, one):
-    """Random scenes incl. boxes spanning many tiles and (one=7) opacity-1 Gaussians whose centre pixel has an
+    """Random scenes incl. boxes spanning many tiles, tile lists longer than one staging round of either kernel (256
+    forward, 32 backward; per-wave hit words of 64 entries) and (one=7) opacity-1 Gaussians whose centre pixel has an
     inclusive product of exactly 0 (dropped pair, gs_model.py:560)."""
     from oracle import dense_render as dr
 
@@ -67,6 +69,15 @@ def test_function_vs_dense_oracle(device, n_gauss, w, h, mh, seed, one):
     if one:
         assert bool((sc["opacity"] == 1.0).any())
     torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    # The backward walks a pixel's list front to back and forms the suffix sum of (g . p) as total - prefix
+    # (DESIGN.md §7 f1): behind ~800 layers the prefix carries ~depth * 2^-24 * |total| of fp32 round-off, which shows
+    # up as absolute noise of a few 1e-5 on gradients whose true value is ~0 (times dx^2 <= 24^2 in the second moments
+    # behind grad_vinv).  The image is unaffected.
+    if n_gauss == 900:  # stated bound of the deep case: 1e-5 of the largest gradient component + 5e-5 absolute
+        for got, want, what in ((go, go64, "grad_opacity"), (gv, gv64, "grad_vinv"), (gl, gl64, "grad_l")):
+            err = (got.double().cpu() - want.double()).abs().max().item()
+            assert err <= TOL * want.abs().max().item() + 5e-5, (what, err, want.abs().max().item())
+        return
     _close(go, go64, go64.abs().mean().item(), "grad_opacity")
     _close(gv, gv64, gv64.abs().mean().item(), "grad_vinv")
     _close(gl, gl64, gl64.abs().mean().item(), "grad_l")

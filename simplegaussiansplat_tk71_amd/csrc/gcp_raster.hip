@@ -347,9 +347,6 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
          (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-#ifndef GCP_FWD_EARLY_LOADS
-#define GCP_FWD_EARLY_LOADS 1
-#endif
 #ifndef GCP_DPP_ASM
 #define GCP_DPP_ASM 1
 #endif
@@ -381,37 +378,35 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
     __syncthreads();
     stage_entries<kStage, false>(a, s, base, cnt, (tile % a.tiles_x) * kTile, (tile / a.tiles_x) * kTile);
     __syncthreads();
-    // Only the entries whose rows reach this wave (hits[w]), in list order.
+    // Only the entries whose rows reach this wave (hits[w]), in list order.  Every listed entry is used, so all
+    // three of its LDS records are read together, ahead of the membership branch.  (Reading one entry ahead of the
+    // blend, with two register sets, changes nothing: 93 % of the launch is VALU issue.)
+    auto blend = [&](const float4& ge, const float4& vi, const float4& co) {
+      if ((__float_as_uint(ge.w) & lane_bits) == lane_bits) {  // (the branch-free form of the backward is 4 % slower here)
+        const float dx = fx - ge.x, dy = fy - ge.y;
+        // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
+        const float t0 = dx * vi.x + dy * vi.z;
+        const float t1 = dx * vi.y + dy * vi.w;
+        const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
+        const float anti = 1.0f - ge.z * g;             // gs_model.py:535
+        const float incl = T * anti;                    // inclusive grouped cumprod
+        if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
+          const float wgt = T * ge.z * g;               // gs_model.py:500
+          c0 += wgt * co.x; c1 += wgt * co.y; c2 += wgt * co.z;
+        }
+        T = incl;
+      }
+    };
     const int chunks = (cnt + 63) >> 6;
     for (int c = 0; c < chunks; ++c) {
       unsigned long long hits = uniform64(s.hits[w][c]);
+      if (!hits) continue;
       while (hits) {
         const int k = c * 64 + __builtin_ctzll(hits);
         hits &= hits - 1;
-        const float4 ge = s.geo[k];
-#if GCP_FWD_EARLY_LOADS
-        const float4 vi = s.vin[k];  // every listed entry reaches this wave: all three LDS reads in one round trip
-        const float4 co = s.col[k];
-        asm volatile("" :: "v"(vi.x), "v"(co.x));  // keep them ahead of the branch
-        if ((__float_as_uint(ge.w) & lane_bits) == lane_bits) {  // (the branch-free form of the backward is 4 % slower here)
-#else
-        if ((__float_as_uint(ge.w) & lane_bits) == lane_bits) {  // (the branch-free form of the backward is 4 % slower here)
-          const float4 vi = s.vin[k];
-          const float4 co = s.col[k];
-#endif
-          const float dx = fx - ge.x, dy = fy - ge.y;
-          // (d Λ) d^T with the association of the reference's two matmuls (gs_model.py:495)
-          const float t0 = dx * vi.x + dy * vi.z;
-          const float t1 = dx * vi.y + dy * vi.w;
-          const float g = __builtin_amdgcn_exp2f(t0 * dx + t1 * dy);  // = exp(-0.5 (d Λ) d^T), gs_model.py:495
-          const float anti = 1.0f - ge.z * g;             // gs_model.py:535
-          const float incl = T * anti;                    // inclusive grouped cumprod
-          if (incl != 0.0f) {                             // gs_model.py:560: dropped when exactly 0
-            const float wgt = T * ge.z * g;               // gs_model.py:500
-            c0 += wgt * co.x; c1 += wgt * co.y; c2 += wgt * co.z;
-          }
-          T = incl;
-        }
+        const float4 ge = s.geo[k], vi = s.vin[k], co = s.col[k];
+        asm volatile("" :: "v"(vi.x), "v"(co.x));  // keep the reads ahead of the branch
+        blend(ge, vi, co);
       }
     }
   }

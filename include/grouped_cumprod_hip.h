@@ -195,7 +195,9 @@ int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const floa
 /* f1 backward: gradients of <image, grad_image> w.r.t. mean [N,2], vinv [N,2,2], opacity [N],
  * l_d [N,3].  `image` is the forward result.  Replaces _backward_batch + grad_list_to_gause
  * (gs_model.py:627-663, :733-783).  grad_l is the TRUE gradient (the reference's is
- * channel-collapsed, gs_model.py:710-712,:763-766).  ws: gcp_blend_backward_workspace_bytes(K). */
+ * channel-collapsed, gs_model.py:710-712,:763-766).  The per-pixel suffix sums (gs_model.py:716-722) are clamped to
+ * their analytic bound T * sum|grad| * max|l_d|, so Gaussians behind an opaque stack get gradients of the size of their
+ * transmittance rather than fp32 round-off of the pixel total.  ws: gcp_blend_backward_workspace_bytes(K). */
 size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs);
 int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
                        const float* vinv, const float* opacity, const float* l_d, int64_t n_gauss,

@@ -347,6 +347,9 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
          (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+#ifndef GCP_SUFFIX_CLAMP
+#define GCP_SUFFIX_CLAMP 1
+#endif
 #ifndef GCP_DPP_ASM
 #define GCP_DPP_ASM 1
 #endif
@@ -416,10 +419,21 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   }
 }
 
+// max |v| over n floats as the bit pattern of a non-negative float (integer max of such patterns = float max; order
+// independent, so deterministic)
+__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ v, i64 n, unsigned* __restrict__ out) {
+  float m = 0.0f;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
 // Backward: per (tile, entry) partial sums, written to the entry's Gaussian-major slot.
 __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int* __restrict__ tile_off,
                                                    const float* __restrict__ image,
                                                    const float* __restrict__ grad_image,
+                                                   const float* __restrict__ l_abs_max,
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
@@ -444,6 +458,11 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     g0 = grad_image[o]; g1 = grad_image[o + 1]; g2 = grad_image[o + 2];
     gC = g0 * image[o] + g1 * image[o + 1] + g2 * image[o + 2];  // sum over the pixel's pairs of (g . p)
   }
+  // |suffix sum behind entry k| <= T_{k+1} * sum_c |g_c| * max |l|: the suffix is formed as total - prefix and carries
+  // the prefix's round-off (~depth * 2^-24 * |total|); clamping it to this bound keeps the gradients of Gaussians behind
+  // an opaque stack at the size of their transmittance instead of at that noise floor (Adam would normalise the noise
+  // into full-size steps)
+  const float gL = (fabsf(g0) + fabsf(g1) + fabsf(g2)) * l_abs_max[0];
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
   const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
   float* const row_slot = &s_part[0][(w * 4 + (lane >> 4)) * kRowSlots + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
@@ -483,7 +502,12 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
       const float wgt = keep ? T * og : 0.0f;
       const float gp = wgt * (g0 * co.x + g1 * co.y + g2 * co.z);  // sum_c g_c p_c with p = wgt * l (gs_model.py:632)
       acc += gp;
-      const float S = gC - acc;                          // exclusive suffix sum of gp (gs_model.py:716-722)
+#if GCP_SUFFIX_CLAMP
+      const float bnd = incl * gL;
+      const float S = __builtin_amdgcn_fmed3f(gC - acc, -bnd, bnd);  // exclusive suffix sum of gp (gs_model.py:716-722)
+#else
+      const float S = gC - acc;
+#endif
       const float sa = S * __builtin_amdgcn_rcpf(anti);   // S / anti (v_rcp_f32, 1 ulp)
       float r_o = keep ? gp * co.w - g * sa : 0.0f;       // gs_model.py:733-740 (gp / o for o != 0)
       float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;  // true dL/dl (reference: gp / l, Q2)
@@ -826,7 +850,8 @@ int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const floa
 }
 
 size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs) {
-  return align256((size_t)(n_tile_pairs > 0 ? n_tile_pairs : 1) * kGradVals * sizeof(float));
+  // per-entry partial sums, then one 256-byte slot for max |l_d| (the bound of the suffix sums)
+  return align256((size_t)(n_tile_pairs > 0 ? n_tile_pairs : 1) * kGradVals * sizeof(float)) + 256;
 }
 
 int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy, const float* vinv,
@@ -847,8 +872,12 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
   const TileGrid tg = tile_grid(width, height);
   float* partial = (float*)ws;
   if (n_tile_pairs > 0) {
+    unsigned* lmax = (unsigned*)((char*)ws + gcp_blend_backward_workspace_bytes(n_tile_pairs) - 256);
+    GCP_HIP(hipMemsetAsync(lmax, 0, sizeof(unsigned), stream));
+    const i64 nl = 3 * (i64)n_gauss;
+    hipLaunchKernelGGL(k_abs_max, dim3((unsigned)((nl + 255) / 256 < 1024 ? (nl + 255) / 256 : 1024)), dim3(256), 0, stream, l_d, nl, lmax);
     hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, tile_off, image,
-                       grad_image, partial);
+                       grad_image, (const float*)lmax, partial);
     GCP_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream,

@@ -106,7 +106,7 @@ def test_raster_argument_validation_needs_no_gpu():
     assert lib.gcp_tile_grid(-1, 5, ctypes.byref(tx), ctypes.byref(ty)) == 1
     assert lib.gcp_bin_workspace_bytes(1000, 3000) % 256 == 0
     assert lib.gcp_bin_workspace_bytes(1_000_000, 3_000_000) < 64 << 20
-    assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4  # 9 floats per (tile, Gaussian) entry
+    assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4 + 256  # 9 floats per (tile, Gaussian) entry + one slot
     k = ctypes.c_int64(-1)
     assert lib.gcp_bin_tiles_count(None, None, -1, 10, 10, None, ctypes.byref(k), None, 0, None) == 1
     assert lib.gcp_blend_forward(None, None, None, None, None, None, 5, 10, 10, None, None, None, None) == 1

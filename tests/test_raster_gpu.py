@@ -373,3 +373,34 @@ def test_render_cameras_on_two_streams_equals_sequential(device):
     torch.cuda.synchronize()
     for a, b in zip(seq, par):
         assert torch.equal(a, b)
+
+
+def test_gaussians_behind_an_opaque_stack_get_transmittance_sized_gradients(device):
+    """The backward forms a pixel's suffix sums as total - prefix; the prefix's fp32 round-off (~1e-7 of the total) would
+    otherwise be the gradient of every Gaussian behind an opaque stack — pure noise that Adam normalises into full-size
+    steps.  The suffix is clamped to its analytic bound T * sum|g| * max|l| (include/grouped_cumprod_hip.h), so such
+    gradients are of the size of the transmittance, as in the reference's reverse scan."""
+    w = h = 31
+    n_front, n_back = 60, 40
+    n = n_front + n_back
+    g = torch.Generator().manual_seed(3)
+    start = torch.zeros(n, 2, dtype=torch.int32)
+    end = torch.full((n, 2), w, dtype=torch.int32)
+    mean = torch.randint(8, 24, (n, 2), generator=g).to(torch.int32)
+    vinv = (torch.eye(2) * 2e-3).repeat(n, 1, 1)  # wide: g ~ 1 over the whole image
+    opacity = torch.cat([torch.full((n_front, 1), 0.6), 0.2 + 0.6 * torch.rand(n_back, 1, generator=g)])
+    sc = {"start": start, "end": end, "mean": mean, "vinv": vinv, "opacity": opacity, "l_d": 0.1 + torch.rand(n, 3, generator=g),
+          "boxsize": torch.prod((end - start + 1).long(), 1), "width": w, "height": h,
+          "wimg": torch.randn(h + 1, w + 1, 3, generator=g)}
+    from oracle import dense_render as dr
+
+    img, gv, go, gl = _apply(device, sc)
+    i64, gv64, go64, gl64 = dr.render_with_grads(start, end, mean, vinv, opacity, sc["l_d"], w, h, sc["wimg"])
+    torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
+        hidden_true = want[n_front:].abs().max().item()
+        assert hidden_true < 1e-8, (name, hidden_true)                   # far below the ~1e-6 round-off of the pixel totals
+        hidden_got = got[n_front:].abs().max().item()
+        assert hidden_got <= 100 * hidden_true, (name, hidden_got, hidden_true)  # ... and of that size here too (the bound,
+        # not the exact suffix, is what the clamp guarantees)
+        assert want[:n_front].abs().max().item() > 1e-3, name               # the visible ones still learn

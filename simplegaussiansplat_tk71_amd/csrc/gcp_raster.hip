@@ -422,11 +422,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
 // max |v| over n floats as the bit pattern of a non-negative float (integer max of such patterns = float max; order
 // independent, so deterministic)
 __global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ v, i64 n, unsigned* __restrict__ out) {
+  __shared__ float s_m[4];
   float m = 0.0f;
   for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per block (256 in all): same-address atomics serialise at ~10 ns each
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
 }
 
 // Backward: per (tile, entry) partial sums, written to the entry's Gaussian-major slot.
@@ -875,7 +879,7 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
     unsigned* lmax = (unsigned*)((char*)ws + gcp_blend_backward_workspace_bytes(n_tile_pairs) - 256);
     GCP_HIP(hipMemsetAsync(lmax, 0, sizeof(unsigned), stream));
     const i64 nl = 3 * (i64)n_gauss;
-    hipLaunchKernelGGL(k_abs_max, dim3((unsigned)((nl + 255) / 256 < 1024 ? (nl + 255) / 256 : 1024)), dim3(256), 0, stream, l_d, nl, lmax);
+    hipLaunchKernelGGL(k_abs_max, dim3((unsigned)((nl + 255) / 256 < 256 ? (nl + 255) / 256 : 256)), dim3(256), 0, stream, l_d, nl, lmax);
     hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, tile_off, image,
                        grad_image, (const float*)lmax, partial);
     GCP_HIP(hipGetLastError());

@@ -215,14 +215,13 @@ def main():
     # the HIP library is prebuilt in-tree; if it is missing, local rank 0 builds it and the others wait
     from simplegaussiansplat_tk71_amd import _build
 
-    if not os.path.exists(_build.LIB_PATH):
+    if _build.is_stale():  # missing, or built from other sources than this checkout's
         if local_rank == 0:
             _build.build_hip_library(force=True)
         else:
             t_wait = time.time()
-            while not os.path.exists(_build.LIB_PATH) and time.time() - t_wait < 300:
-                time.sleep(1.0)
-            time.sleep(2.0)  # let the linker finish writing
+            while _build.is_stale() and time.time() - t_wait < 600:
+                time.sleep(2.0)
     import grouped_cumprod as gc
     from simplegaussiansplat_tk71_amd import synthetic
 

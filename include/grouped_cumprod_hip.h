@@ -16,8 +16,14 @@
  *   - a "group" (one pixel's depth-sorted splat list) is a maximal run of equal
  *     ADJACENT keys — keys need not be globally sorted
  *     (thrust::equal_to<int>, grouped_cumprod_forward.cu:21);
- *   - outputs are caller-allocated and overwritten in place; nothing is
- *     retained by the library;
+ *   - outputs are caller-allocated and overwritten; nothing is retained by the
+ *     library.  An output array must NOT overlap any input array of the same
+ *     call (no in-place scan: blocks re-read raw inputs of the neighbouring
+ *     tile while that tile's block is already storing) — overlapping ranges
+ *     return GCP_ERR_INVALID_ARGUMENT.  (The reference's
+ *     thrust::inclusive_scan_by_key tolerates y == x,
+ *     grouped_cumprod_forward.cu:17-23; none of its callers uses that:
+ *     gs_model.py:549 and cuda_test.py:22,25 allocate fresh outputs.)
  *   - launches are asynchronous on `stream`; no host synchronisation, no
  *     allocation when a workspace is supplied (graph-capturable);
  *   - every function returns GCP_OK (0) or a GCP_ERR_* code; n == 0 is a no-op;
@@ -44,7 +50,7 @@ extern "C" {
 #endif
 
 #define GCP_OK 0
-#define GCP_ERR_INVALID_ARGUMENT 1 /* NULL pointer with n > 0, negative n, n too large */
+#define GCP_ERR_INVALID_ARGUMENT 1 /* NULL pointer with n > 0, negative n, n too large, output overlapping an input */
 #define GCP_ERR_WORKSPACE 2        /* workspace too small / misaligned */
 #define GCP_ERR_HIP 3              /* a HIP call failed: see gcp_last_hip_error() */
 
@@ -52,6 +58,10 @@ extern "C" {
 
 /* ABI version of the loaded library (== GCP_ABI_VERSION it was built with). */
 int gcp_abi_version(void);
+
+/* Hash of the kernel sources + headers + compile flags this binary was built from (the build recipe passes it as
+ * -DGCP_SOURCE_HASH); the Python binding refuses a library whose hash differs from the checkout's. */
+const char* gcp_source_hash(void);
 
 /* hipError_t (as int) of the most recent failing HIP call on this host thread, 0 if none. */
 int gcp_last_hip_error(void);

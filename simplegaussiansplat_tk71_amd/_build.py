@@ -5,6 +5,7 @@ cuda_kernel.cpp + three .cu files).  The product here is a C-ABI shared library
 (no torch types, see include/grouped_cumprod_hip.h) compiled by one explicit
 hipcc invocation; Python binds it with ctypes (_lib.py).
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -37,12 +38,32 @@ def find_hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
-def is_stale():
+def source_hash():
+    """sha256 over the kernel sources, the headers and the compile flags: compiled into the library
+    (gcp_source_hash()) so a binary older than the checkout is detected whatever the file times say — the .so is
+    git-ignored and travels to the GPU box separately from the sources."""
+    h = hashlib.sha256()
+    for path in [*SRCS, *HDRS, os.path.join(INCLUDE, "grouped_cumprod_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:32]
+
+
+def built_hash():
+    """Hash string compiled into the library on disk, or None (missing / older than this mechanism).  Read from the
+    file's bytes, not through dlopen: a library loaded once stays mapped under its path even after a rebuild."""
     if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [*SRCS, *HDRS, os.path.join(INCLUDE, "grouped_cumprod_hip.h"), os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    import re
+
+    with open(LIB_PATH, "rb") as f:
+        m = re.search(rb"GCPSRCHASH:([0-9a-f]{32})", f.read())
+    return m.group(1).decode() if m else None
+
+
+def is_stale():
+    return built_hash() != source_hash()
 
 
 def build_hip_library(force=False, verbose=False, extra_flags=()):
@@ -50,7 +71,8 @@ def build_hip_library(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc(), *HIPCC_FLAGS, *extra_flags, "-I", INCLUDE, "-o", LIB_PATH, *SRCS]
+    cmd = [find_hipcc(), *HIPCC_FLAGS, *extra_flags, f'-DGCP_SOURCE_HASH="{source_hash()}"', "-I", INCLUDE, "-o", LIB_PATH,
+           *SRCS]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

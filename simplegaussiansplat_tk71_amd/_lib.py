@@ -7,6 +7,7 @@ fails when its extension is not built (reference: gs_model.py:8).
 import ctypes
 import os
 
+from . import _build
 from ._build import LIB_PATH
 
 _c_void_p = ctypes.c_void_p
@@ -17,6 +18,7 @@ _i32 = ctypes.c_int32
 # name -> (restype, argtypes); must list every symbol include/grouped_cumprod_hip.h declares
 SIGNATURES = {
     "gcp_abi_version": (ctypes.c_int, []),
+    "gcp_source_hash": (ctypes.c_char_p, []),
     "gcp_last_hip_error": (ctypes.c_int, []),
     "gcp_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "gcp_workspace_bytes": (_sz, [_i64]),
@@ -85,6 +87,12 @@ def load():
     if _lib is not None:
         return _lib
     path = os.environ.get("GCP_LIBRARY", LIB_PATH)
+    if path == LIB_PATH and os.path.exists(path) and _build.is_stale():
+        # a binary older than the sources of this checkout: rebuild where hipcc exists, refuse otherwise
+        try:
+            _build.build_hip_library(force=True)
+        except RuntimeError as e:
+            raise ImportError(f"{path} was built from other sources than this checkout's and cannot be rebuilt: {e}") from e
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: build it with `python setup.py build_ext --inplace` "

@@ -748,6 +748,16 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   if (n == 0) return GCP_OK;
   if (!in0 || !key || !out) return GCP_ERR_INVALID_ARGUMENT;
   if (Mode<MODE>::kBwd && (!in1 || !in2)) return GCP_ERR_INVALID_ARGUMENT;
+  // No aliasing: the look-back re-reads the neighbouring tile's RAW inputs while that tile's block may already be
+  // storing its outputs, so an output range that shares bytes with an input range races between blocks.
+  {
+    const uintptr_t o0 = (uintptr_t)out, o1 = o0 + (uintptr_t)n * 4u;
+    const void* ins[4] = {in0, in1, in2, key};
+    for (const void* q : ins) {
+      const uintptr_t q0 = (uintptr_t)q;
+      if (q && o0 < q0 + (uintptr_t)n * 4u && q0 < o1) return GCP_ERR_INVALID_ARGUMENT;
+    }
+  }
   const i64 ntiles = (n + kTile - 1) / kTile;
   if (ntiles > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
 
@@ -799,6 +809,14 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
 extern "C" {
 
 int gcp_abi_version(void) { return GCP_ABI_VERSION; }
+
+#ifndef GCP_SOURCE_HASH
+#define GCP_SOURCE_HASH "unknown"
+#endif
+const char* gcp_source_hash(void) {
+  static const char tagged[] = "GCPSRCHASH:" GCP_SOURCE_HASH;  // the tag lets the build recipe find it in the file
+  return tagged + 11;
+}
 
 int gcp_last_hip_error(void) { return gcp::t_last_hip_error; }
 

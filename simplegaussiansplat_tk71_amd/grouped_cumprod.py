@@ -53,6 +53,21 @@ def _check_tensor(t, name, dtype, device, numel=None):
         _require(t.numel() == numel, f"{name}: {t.numel()} elements, expected {numel}")
 
 
+def _no_alias(out, out_name, *inputs):
+    """The scans re-read raw inputs of the NEIGHBOURING tile (look-back) while other blocks already store their
+    outputs, so an output that shares bytes with an input races between blocks.  The reference's
+    thrust::inclusive_scan_by_key is legal in place (grouped_cumprod_forward.cu:17-23); here it is rejected loudly
+    instead of returning nondeterministic values."""
+    o0 = out.data_ptr()
+    o1 = o0 + out.numel() * out.element_size()
+    for t, name in inputs:
+        t0 = t.data_ptr()
+        t1 = t0 + t.numel() * t.element_size()
+        _require(not (o0 < t1 and t0 < o1),
+                 f"{out_name}: overlaps {name} in memory; in-place / aliased outputs are not supported "
+                 "(allocate a separate output tensor)")
+
+
 def _workspace(device, stream_handle, n):
     """Scratch of the current (device, stream): reused across calls, grown geometrically."""
     key = (device.index, stream_handle)
@@ -87,6 +102,7 @@ def _forward(fn_name, x, key, y):
     _check_tensor(y, "out", torch.float32, dev, n)
     if n == 0:
         return
+    _no_alias(y, "out", (x, "unti_opacity"), (key, "pixel_index"))
     _launch(fn_name, dev, n, (x.data_ptr(), key.data_ptr(), y.data_ptr()))
 
 
@@ -120,6 +136,7 @@ def _forward_carry(fn_name, x, inv, carry, y):
     if n == 0:
         return
     _require(carry.numel() > 0, "carry: empty for a non-empty input")
+    _no_alias(y, "out", (x, "x"), (inv, "inv"), (carry, "carry"))
     _launch(fn_name, dev, n, (x.data_ptr(), inv.data_ptr(), carry.data_ptr(), y.data_ptr()), (carry.numel(),))
 
 
@@ -158,6 +175,8 @@ def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_l
     if n == 0:
         return
     _require(inv_len.numel() > 0, "inv_len: empty for a non-empty input")
+    _no_alias(grad_in, "grad_in", (param, "param"), (param_cumprod, "param_cumprod"), (grad_out, "grad_out"), (inv, "inv"),
+              (inv_len, "inv_len"))
     _launch(
         "gcp_cumprod_backward",
         dev,

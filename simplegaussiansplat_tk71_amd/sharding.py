@@ -172,6 +172,42 @@ def band_view(startpoint: torch.Tensor, endpoint: torch.Tensor, mean: torch.Tens
     return s, e, m, y1 - y0
 
 
+def band_is_empty(band: tuple) -> bool:
+    return band[1] < band[0]
+
+
+def _hip_blend(s, e, m, variance_inverse, opacity, l_d, width, height, grad_band):
+    from . import raster
+
+    bins = raster.bin_tiles(s, e, width, height)
+    img = raster.blend_forward(bins, s, e, m, variance_inverse, opacity, l_d)
+    if grad_band is None:
+        return img, None
+    g_mean, g_vinv, g_op, g_l = raster.blend_backward(bins, s, e, m, variance_inverse, opacity, l_d, img, grad_band)
+    return img, (g_vinv, g_op, g_l)
+
+
+def blend_band(band, startpoint, endpoint, mean, variance_inverse, opacity, l_d, width, grad_band=None, blend=None):
+    """One rank's share of the band-sharded Function: the image rows of `band` and, when `grad_band` (dL/dI rows of
+    the band) is given, this band's share of the per-Gaussian gradients (variance_inverse, opacity, l_d).
+    A rank whose band is EMPTY (more ranks than 16-pixel tile rows) launches nothing and returns a zero-row image and
+    zero gradients, so it still joins gather_bands / scatter_bands / allreduce_gaussian_grads with the right shapes
+    instead of raising while the others wait in the collective.
+    `blend(s, e, m, vinv, opacity, l_d, width, height, grad_band)` defaults to the HIP kernels (raster.py)."""
+    n = startpoint.size(0)
+    if band_is_empty(band):
+        f = variance_inverse
+        img = f.new_zeros((0, int(width) + 1, 3))
+        if grad_band is None:
+            return img, None
+        return img, (f.new_zeros((n, 2, 2)), f.new_zeros(tuple(opacity.shape)), f.new_zeros((n, 3)))
+    s, e, m, bh = band_view(startpoint, endpoint, mean, band)
+    img, grads = (blend or _hip_blend)(s, e, m, variance_inverse, opacity, l_d, int(width), bh, grad_band)
+    if grads is not None:
+        grads = (grads[0], grads[1].reshape(opacity.shape), grads[2])
+    return img, grads
+
+
 def gather_bands(band_image: torch.Tensor, bands: Sequence[tuple], dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """ONE gather of row bands [(y1-y0+1), W+1, C] into the frame [(H+1), W+1, C] on `dst`."""
     world = dist.get_world_size(group)

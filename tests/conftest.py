@@ -17,7 +17,7 @@ def pytest_sessionstart(session):
     (hipcc cross-compiles without a GPU).  Tests never fall back to anything else."""
     from simplegaussiansplat_tk71_amd import _build
 
-    if not os.path.exists(_build.LIB_PATH):
+    if _build.is_stale():  # missing, or built from other sources than this checkout's (hash compiled into the .so)
         _build.build_hip_library(force=True)
 
 

@@ -127,7 +127,7 @@ def test_row_bands_cover_the_frame_on_tile_boundaries():
         assert all(y0 % 16 == 0 for (y0, y1) in bands if y1 >= y0)
 
 
-def _band_worker(rank, world, port, q):
+def _band_worker(rank, world, port, q, w=40, h=45):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -135,14 +135,19 @@ def _band_worker(rank, world, port, q):
         from oracle import dense_render as dr
         from tests.util import make_scene
 
-        w, h = 40, 45
         sc = make_scene(60, w, h, 9, seed=3)
         bands = sharding.row_bands(h, world)
-        s, e, m, bh = sharding.band_view(sc["start"], sc["end"], sc["mean"], bands[rank])
+        y0, y1 = bands[rank]
         gI_full = sc["wimg"].double() if rank == 0 else None
-        like = torch.zeros(bh + 1, w + 1, 3, dtype=torch.float64)
+        like = torch.zeros(max(y1 - y0 + 1, 0), w + 1, 3, dtype=torch.float64)
         gI = sharding.scatter_bands(gI_full, bands, like, src=0)  # backward input: dL/dI rows of this band
-        img, gv, go, gl = dr.render_with_grads(s, e, m, sc["vinv"], sc["opacity"], sc["l_d"], w, bh, gI)  # this band only
+
+        def dense(s, e, m, vinv, op, l_d, width, height, grad):  # the dense oracle stands in for the HIP kernels on CPU
+            img, gv, go, gl = dr.render_with_grads(s, e, m, vinv, op, l_d, width, height, grad)
+            return img, (gv, go, gl)
+
+        img, (gv, go, gl) = sharding.blend_band(bands[rank], sc["start"], sc["end"], sc["mean"], sc["vinv"].double(),
+                                                sc["opacity"].double(), sc["l_d"].double(), w, gI, blend=dense)
         frame = sharding.gather_bands(img, bands, dst=0)
         gv, go, gl = sharding.allreduce_gaussian_grads(gv, go, gl)
         if rank == 0:
@@ -164,6 +169,25 @@ def test_two_rank_gloo_band_sharded_function():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_band_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    assert q.get(timeout=150) is True
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+
+
+@pytest.mark.timeout(180)
+def test_more_ranks_than_tile_rows_empty_bands_join_the_collectives():
+    """A 30-row frame has two 16-pixel tile rows; with 3 ranks one band is empty.  That rank must contribute a
+    zero-row band and zero gradients and still enter every collective (it used to raise on a negative height while
+    the others waited)."""
+    world = 3
+    assert any(sharding.band_is_empty(b) for b in sharding.row_bands(29, world))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, q, 40, 29)) for r in range(world)]
     for pr in procs:
         pr.start()
     assert q.get(timeout=150) is True

@@ -161,6 +161,41 @@ def test_argument_errors(device):
         gc.grouped_cumprod_forward(x[::2], k[::2], x[::2])  # non-contiguous
 
 
+def test_outputs_that_alias_inputs_are_rejected(device):
+    """Thrust's inclusive_scan_by_key is legal in place (grouped_cumprod_forward.cu:17-23); this library's blocks
+    re-read the neighbouring tile's raw inputs, so an output sharing bytes with an input is refused — by the Python
+    module (RuntimeError) and by the C ABI itself (GCP_ERR_INVALID_ARGUMENT) — instead of racing."""
+    import ctypes
+
+    from simplegaussiansplat_tk71_amd import _lib
+
+    gc, _ = _mods()
+    n = 10000
+    x = torch.rand(n, device=device)
+    k = torch.zeros(n, device=device, dtype=torch.int32)
+    big = torch.rand(2 * n, device=device)
+    for fn in (gc.grouped_cumprod_forward, gc.grouped_cumsum_forward, gc.grouped_cumsum_reverse):
+        with pytest.raises(RuntimeError, match="overlaps"):
+            fn(x, k, x)                                  # y is x
+        with pytest.raises(RuntimeError, match="overlaps"):
+            fn(big[:n], k, big[n // 2 : n // 2 + n])     # partial overlap of two views
+        fn(big[:n], k, big[n:])                          # adjacent, disjoint views are fine
+    il = torch.tensor([n], device=device, dtype=torch.int32)
+    y = torch.empty_like(x)
+    for bad in (x, y):
+        with pytest.raises(RuntimeError, match="overlaps"):
+            gc.grouped_cumprod_backward(x, y, torch.ones_like(x), k, bad, il)
+    with pytest.raises(RuntimeError, match="overlaps"):
+        gc.grouped_cumprod_forward_carry(x, k, torch.ones(1, device=device), x)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gcp_cumprod_forward(x.data_ptr(), k.data_ptr(), x.data_ptr(), n, None, 0, st) == 1  # GCP_ERR_INVALID_ARGUMENT
+    assert lib.gcp_cumprod_backward(x.data_ptr(), y.data_ptr(), y.data_ptr(), k.data_ptr(), y.data_ptr(), il.data_ptr(), n, 1,
+                                    None, 0, st) == 1
+    assert ctypes.c_int(lib.gcp_cumprod_forward(x.data_ptr(), k.data_ptr(), y.data_ptr(), n, None, 0, st)).value == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dist", ["one_run", "runs9000", "mixed", "geo80"])
 def test_fallback_many_tiles(device, dist):
     """> 256 tiles so every block of the fallback kernel owns a multi-tile range, with groups that

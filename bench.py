@@ -124,9 +124,9 @@ def function_level(dev, workload):
         return r, a.elapsed_time(b) / iters
 
     bins, t_bin = timed(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h))
-    img, t_fwd = timed(lambda: raster.blend_forward(bins, *params))
+    (img, ckpt), t_fwd = timed(lambda: raster.blend_forward(bins, *params, with_checkpoints=True))
     gimg = torch.randn_like(img)
-    _, t_bwd = timed(lambda: raster.blend_backward(bins, *params, img, gimg))
+    _, t_bwd = timed(lambda: raster.blend_backward(bins, *params, ckpt, gimg))
     return {
         "what": "custom_autograd_grouped_cumprod: tile binning + fused blend forward + backward (no pair list materialised)",
         "gaussians": int(sc["start"].size(0)),

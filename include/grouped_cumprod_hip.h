@@ -54,7 +54,7 @@ extern "C" {
 #define GCP_ERR_WORKSPACE 2        /* workspace too small / misaligned */
 #define GCP_ERR_HIP 3              /* a HIP call failed: see gcp_last_hip_error() */
 
-#define GCP_ABI_VERSION 1
+#define GCP_ABI_VERSION 2
 
 /* ABI version of the loaded library (== GCP_ABI_VERSION it was built with). */
 int gcp_abi_version(void);
@@ -196,24 +196,31 @@ int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n
 
 /* f1 forward: image = sum over pairs of T * l * o * g with T the exclusive grouped cumprod of
  * (1 - o g) per pixel in depth order; pairs whose inclusive product is exactly 0 are dropped.
- * Replaces _forward_batch + index_put_(accumulate=True) (gs_model.py:598-624, :510-514). */
+ * Replaces _forward_batch + index_put_(accumulate=True) (gs_model.py:598-624, :510-514).
+ * t_ckpt: NULL (inference), or gcp_blend_checkpoint_floats(K, width, height) floats that receive every pixel's
+ * transmittance at every GCP-internal checkpoint interval of its tile's list — what gcp_blend_backward restarts
+ * its per-chunk front-to-back pass from (the reference keeps the whole M-length T array for that, gs_model.py:691). */
+size_t gcp_blend_checkpoint_floats(int64_t n_tile_pairs, int32_t width, int32_t height);
 int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
                       const float* vinv, const float* opacity, const float* l_d, int64_t n_gauss,
                       int32_t width, int32_t height, const int32_t* tile_start,
-                      const int32_t* tile_list, float* image, void* stream);
+                      const int32_t* tile_list, float* image, float* t_ckpt, void* stream);
 
 /* f1 backward: gradients of <image, grad_image> w.r.t. mean [N,2], vinv [N,2,2], opacity [N],
- * l_d [N,3].  `image` is the forward result.  Replaces _backward_batch + grad_list_to_gause
- * (gs_model.py:627-663, :733-783).  grad_l is the TRUE gradient (the reference's is
- * channel-collapsed, gs_model.py:710-712,:763-766).  The per-pixel suffix sums (gs_model.py:716-722) are clamped to
- * their analytic bound T * sum|grad| * max|l_d|, so Gaussians behind an opaque stack get gradients of the size of their
- * transmittance rather than fp32 round-off of the pixel total.  ws: gcp_blend_backward_workspace_bytes(K). */
+ * l_d [N,3].  `t_ckpt` is what gcp_blend_forward wrote for the same inputs and bins.  Replaces _backward_batch +
+ * grad_list_to_gause (gs_model.py:627-663, :733-783).  Every tile list is walked BACK TO FRONT: the per-pixel
+ * suffix sums the reference takes from a flipped grouped cumsum (gs_model.py:716-722) are carried as
+ * S_k / (1 - o_k g_k) = T_k R_k with R_{k-1} = R_k + o_k g_k (dL/dI . l_k - R_k) (no cancellation, no division), so
+ * a gradient's round-off is relative to the transmittance of its own layer at any depth.  grad_l is the TRUE
+ * gradient (the reference's is channel-collapsed, gs_model.py:710-712,:763-766), and dL/dopacity is the true one
+ * also at opacity == 0 (the reference drops the direct term there, gs_model.py:737-738).
+ * ws: gcp_blend_backward_workspace_bytes(K). */
 size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs);
 int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
                        const float* vinv, const float* opacity, const float* l_d, int64_t n_gauss,
                        int32_t width, int32_t height, const int32_t* tile_off,
                        int64_t n_tile_pairs, const int32_t* tile_start, const int32_t* tile_list,
-                       const float* image, const float* grad_image, float* grad_mean,
+                       const float* t_ckpt, const float* grad_image, float* grad_mean,
                        float* grad_vinv, float* grad_opacity, float* grad_l, void* ws,
                        size_t ws_bytes, void* stream);
 

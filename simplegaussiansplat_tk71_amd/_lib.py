@@ -49,9 +49,10 @@ SIGNATURES = {
         ctypes.c_int,
         [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p],
     ),
+    "gcp_blend_checkpoint_floats": (_sz, [_i64, _i32, _i32]),
     "gcp_blend_forward": (
         ctypes.c_int,
-        [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+        [_c_void_p] * 6 + [_i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     ),
     "gcp_blend_backward_workspace_bytes": (_sz, [_i64]),
     "gcp_blend_backward": (
@@ -76,7 +77,7 @@ SIGNATURES = {
     "gcp_project_backward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32] + [_c_void_p] * 10),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

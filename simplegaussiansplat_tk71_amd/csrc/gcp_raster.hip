@@ -16,9 +16,15 @@
 //       T (the exclusive grouped cumprod of the scan path, sequential per pixel), box-tests,
 //       evaluates g = exp(-0.5 d Λ d^T), and accumulates colour.  Pixels are owned by lanes:
 //       no atomics, deterministic.  A wave skips an entry when no lane is inside its box.
-//       Backward walks FORWARD too: the exclusive suffix sum of (dL/dI . p) the reference gets
-//       from a flipped grouped cumsum (gs_model.py:716-722) equals (dL/dI . I) - inclusive
-//       prefix, and I is the saved forward image.  Per-pair gradients collapse to 7 per-lane values;
+//       Backward walks each tile list BACK TO FRONT in chunks of kStageBwd entries: the exclusive suffix
+//       sum S_k of (dL/dI . p) the reference gets from a flipped grouped cumsum (gs_model.py:716-722)
+//       is carried in the normalised form S_k / (1 - o_k g_k) = T_k * R_k with the recurrence
+//       R_{k-1} = R_k + o_k g_k ((dL/dI . l_k) - R_k)  — a convex combination, no cancellation, no
+//       division — and T_k (the exclusive transmittance) comes from a front-to-back pass over the
+//       chunk that starts from the per-chunk checkpoint the forward kernel saved (T per pixel every
+//       kStageBwd entries).  Every gradient term is T_k times a bounded quantity, so its round-off is
+//       relative to the transmittance of ITS OWN layer whatever the depth.
+//       Per-pair gradients collapse to 7 per-lane values;
 //       they are summed along each pixel row of the tile (16 lanes = one DPP row, 4 fused
 //       v_add_f32_dpp) into LDS, one thread per entry folds the 16 rows (dy is constant along a
 //       row) into the entry's slot in Gaussian-major order, and a last kernel sums each Gaussian's
@@ -45,12 +51,11 @@ using namespace gcp;
 #ifndef GCP_STAGE_BWD
 #define GCP_STAGE_BWD 32
 #endif
-#ifndef GCP_HITS64
-#define GCP_HITS64 (GCP_STAGE_BWD > 32)
-#endif
 constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
 constexpr int kStageBwd = GCP_STAGE_BWD;       // (backward; LDS also holds the per-pixel-row partial sums)
+constexpr int kCkpt = kStageBwd;               // the forward saves every pixel's transmittance every kCkpt list entries
+static_assert(kStage % kCkpt == 0 && 64 % kCkpt == 0 && kCkpt <= 32, "checkpoints fall on hit-word boundaries");
 constexpr int kGradVals = 9;        // per (tile, Gaussian) slot: go, gl0..2, S(c dx), S(c dy), S(c dx dx), S(c dx dy), S(c dy dy)
 constexpr int kRowVals = 7;         // per pixel row in LDS: go, gl0..2, S(c), S(c dx), S(c dx dx)   (dy is constant along a row)
 constexpr int kRowSlots = 8;        // LDS slots per pixel row (the transposed reduction below leaves 8 values in 8 lane classes)
@@ -347,9 +352,6 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
          (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-#ifndef GCP_SUFFIX_CLAMP
-#define GCP_SUFFIX_CLAMP 1
-#endif
 #ifndef GCP_DPP_ASM
 #define GCP_DPP_ASM 1
 #endif
@@ -364,7 +366,17 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 #define GCP_FP_CONTRACT
 #endif
 
-__global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __restrict__ image) {
+// Transmittance checkpoints: chunk q of tile t (list entries [first + q kCkpt, first + (q+1) kCkpt)) owns slot
+// first / kCkpt + t + q, 256 floats (one per pixel of the tile, thread order).  Slots of consecutive tiles never
+// overlap (floor(first/c) + ceil(n/c) <= floor((first+n)/c) + 1), so K / kCkpt + n_tiles + 1 slots hold them all
+// without a separate prefix sum.
+__device__ __forceinline__ i64 ckpt_slot0(int first, int tile) { return (i64)(first / kCkpt) + tile; }
+inline size_t ckpt_floats(i64 n_tile_pairs, int n_tiles) {
+  return (size_t)((n_tile_pairs > 0 ? n_tile_pairs : 0) / kCkpt + n_tiles + 1) * 256u;
+}
+
+template <bool CKPT>
+__global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __restrict__ image, float* __restrict__ t_ckpt) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStage> s;
   const int lane = threadIdx.x & 63;
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   const float fx = (float)px, fy = (float)py;
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  float* const ck = CKPT ? t_ckpt + ckpt_slot0(first, tile) * 256 + threadIdx.x : nullptr;
   float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
   for (int base = first; base < last; base += kStage) {
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStage, last - base));  // scalar loop bound
@@ -402,14 +415,24 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
     };
     const int chunks = (cnt + 63) >> 6;
     for (int c = 0; c < chunks; ++c) {
-      unsigned long long hits = uniform64(s.hits[w][c]);
-      if (!hits) continue;
-      while (hits) {
-        const int k = c * 64 + __builtin_ctzll(hits);
-        hits &= hits - 1;
-        const float4 ge = s.geo[k], vi = s.vin[k], co = s.col[k];
-        asm volatile("" :: "v"(vi.x), "v"(co.x));  // keep the reads ahead of the branch
-        blend(ge, vi, co);
+      const unsigned long long hits64 = uniform64(s.hits[w][c]);
+      if (!CKPT && !hits64) continue;
+#pragma unroll
+      for (int sub = 0; sub < 64 / kCkpt; ++sub) {
+        const int e0 = c * 64 + sub * kCkpt;  // first staged entry of this checkpoint interval
+        if (CKPT) {
+          if (e0 >= cnt) break;  // wave-uniform
+          // the transmittance entering list entry base + e0 (the backward restarts its front-to-back pass from here)
+          ck[(i64)((base - first + e0) / kCkpt) * 256] = T;
+        }
+        unsigned hits = (unsigned)(hits64 >> (sub * kCkpt)) & (unsigned)((1ull << kCkpt) - 1ull);
+        while (hits) {
+          const int k = e0 + __builtin_ctz(hits);
+          hits &= hits - 1;
+          const float4 ge = s.geo[k], vi = s.vin[k], co = s.col[k];
+          asm volatile("" :: "v"(vi.x), "v"(co.x));  // keep the reads ahead of the branch
+          blend(ge, vi, co);
+        }
       }
     }
   }
@@ -419,25 +442,23 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
   }
 }
 
-// max |v| over n floats as the bit pattern of a non-negative float (integer max of such patterns = float max; order
-// independent, so deterministic)
-__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ v, i64 n, unsigned* __restrict__ out) {
-  __shared__ float s_m[4];
-  float m = 0.0f;
-  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-  __syncthreads();
-  // one atomic per block (256 in all): same-address atomics serialise at ~10 ns each
-  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
-}
-
 // Backward: per (tile, entry) partial sums, written to the entry's Gaussian-major slot.
+//
+// Per pixel, with k running over the list entries whose box holds the pixel, T_k the exclusive transmittance,
+// a_k = o_k g_k, c_k = (dL/dI . l_k), p_k = T_k a_k l_k (gs_model.py:500):
+//   S_k = sum_{j>k} (dL/dI . p_j)                    exclusive suffix sum, gs_model.py:716-722
+//   S_k / (1 - a_k) = T_k R_k,   R_{k-1} = a_k c_k + (1 - a_k) R_k = R_k + a_k (c_k - R_k),   R_last = 0
+//   dL/do_k    = T_k g_k (c_k - R_k)                 gs_model.py:733-740   (= gp/o - (g/anti) S)
+//   "common"_k = T_k a_k (c_k - R_k)                 gs_model.py:747-748, :757-758   (= gp - (a/anti) S)
+//   dL/dl_k    = dL/dI T_k a_k                       (true gradient; the reference's is channel-collapsed, Q2)
+// The list is walked back to front in chunks of kStageBwd entries; inside a chunk pass A runs front to back from
+// the forward kernel's checkpoint and leaves (T_k, g_k) of every entry in registers (g_k = 0 where the pixel is
+// outside the box or the pair was dropped, gs_model.py:560 — such an entry then contributes exactly nothing below),
+// pass B runs back to front with the recurrence.  No subtraction of accumulated sums, no division: every term is
+// T_k times a convex combination of the c_j, so its round-off is relative to the layer's own transmittance.
 __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int* __restrict__ tile_off,
-                                                   const float* __restrict__ image,
+                                                   const float* __restrict__ t_ckpt,
                                                    const float* __restrict__ grad_image,
-                                                   const float* __restrict__ l_abs_max,
                                                    float* __restrict__ partial /*[K][kGradVals]*/) {
   GCP_FP_CONTRACT
   __shared__ Staged<kStageBwd> s;
@@ -456,76 +477,111 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   const int py = tty * kTile + w * 4 + (lane >> 4);
   const float fx = (float)px, fy = (float)py;
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
-  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, gC = 0.0f;
+  float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
   if (px <= a.W && py <= a.H) {
     const i64 o = ((i64)py * (a.W + 1) + px) * 3;
     g0 = grad_image[o]; g1 = grad_image[o + 1]; g2 = grad_image[o + 2];
-    gC = g0 * image[o] + g1 * image[o + 1] + g2 * image[o + 2];  // sum over the pixel's pairs of (g . p)
   }
-  // |suffix sum behind entry k| <= T_{k+1} * sum_c |g_c| * max |l|: the suffix is formed as total - prefix and carries
-  // the prefix's round-off (~depth * 2^-24 * |total|); clamping it to this bound keeps the gradients of Gaussians behind
-  // an opaque stack at the size of their transmittance instead of at that noise floor (Adam would normalise the noise
-  // into full-size steps)
-  const float gL = (fabsf(g0) + fabsf(g1) + fabsf(g2)) * l_abs_max[0];
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + w * 4 + (lane >> 4)));
-  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
-  float* const row_slot = &s_part[0][(w * 4 + (lane >> 4)) * kRowSlots + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)];
-  float T = 1.0f, acc = 0.0f;
-  for (int base = first; base < last; base += kStageBwd) {
+  const bool b1 = lane & 2;
+#if !GCP_DPP_ASM
+  const bool b3 = lane & 8, b2 = lane & 4;
+#endif
+  float* const row_slot = &s_part[0][(w * 4 + (lane >> 4)) * kRowSlots + ((lane & 2) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 8) ? 1 : 0)];
+  const float* const ck = t_ckpt + ckpt_slot0(first, tile) * 256 + threadIdx.x;
+  static_assert(kStageBwd <= 32, "one 32-bit word of hits per wave");
+  const int nchunks = (last - first + kStageBwd - 1) / kStageBwd;
+  float R = 0.0f;  // R_k of the deepest entry handled so far (the suffix behind the end of the list is empty)
+  for (int q = nchunks - 1; q >= 0; --q) {
+    const int base = first + q * kStageBwd;
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
+    float T = 1.0f;
+    if (q > 0) T = ck[(i64)q * 256];  // issued ahead of the staging: its latency hides behind the barrier
     __syncthreads();
     stage_entries<kStageBwd, true>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();
-    // only the entries whose rows reach this wave, in list order (the finalize below skips this wave's rows for the
-    // others, so nothing needs zeroing)
-#if GCP_HITS64
-    unsigned long long hits = uniform64(s.hits[w][0]);
-    while (hits) {
-      const int k = __builtin_ctzll(hits);
-      hits &= hits - 1;
-#else
-    static_assert(kStageBwd <= 32, "one 32-bit word of hits per wave");
-    unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s.hits[w][0]);
-    while (hits) {
-      const int k = __builtin_ctz(hits);
-      hits &= hits - 1;
+    // only the entries whose rows reach this wave (the fold below skips this wave's rows for the others, so nothing
+    // needs zeroing).  The wave walks the set bits of its hit word on the scalar unit; the loops are unrolled over the
+    // POSITION j in that walk so that Tk[] / gk[] stay in registers, and the LDS records of the next listed entry are
+    // requested before the current one is evaluated (with three or four waves per SIMD an exposed LDS round trip per
+    // entry costs a third of the kernel).
+    const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s.hits[w][0]);
+    const int nh = __builtin_popcount(hits);
+#ifndef GCP_BWD_SAVE_G
+#define GCP_BWD_SAVE_G 0
 #endif
-      // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
-      const float4 ge = s.geo[k];
-      const float4 vi = s.vin[k];
-      const float4 co = s.col[k];
-      const bool in = (__float_as_uint(ge.w) & lane_bits) == lane_bits;
-      const float dx = fx - ge.x, dy = fy - ge.y;
-      // (d Λ) d^T (gs_model.py:495) as a dx^2 + (b + c) dx dy + d dy^2
-      const float g = __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy);
-      const float op = ge.z;
-      const float og = op * g;
-      const float anti = 1.0f - op * g;                  // one fma, as in the forward: both traversals see the same T
-      const float incl = T * anti;
-      const bool keep = in & (incl != 0.0f);
-      const float wgt = keep ? T * og : 0.0f;
-      const float gp = wgt * (g0 * co.x + g1 * co.y + g2 * co.z);  // sum_c g_c p_c with p = wgt * l (gs_model.py:632)
-      acc += gp;
-#if GCP_SUFFIX_CLAMP
-      const float bnd = incl * gL;
-      const float S = __builtin_amdgcn_fmed3f(gC - acc, -bnd, bnd);  // exclusive suffix sum of gp (gs_model.py:716-722)
+    // GCP_BWD_SAVE_G 0 (default): pass B recomputes the kernel value instead of keeping it — 32 VGPRs fewer (four waves
+    // per SIMD instead of three) for 8 more VALU per entry: 0.96 vs 1.06 ms at cfg3.  A dropped / outside pair is then
+    // marked by Tk = 0, which is also what a fully occluded pair has: the same zeros either way.
+    float Tk[kStageBwd];
+    float gk[GCP_BWD_SAVE_G ? kStageBwd : 1];
+    // ---- pass A: front to back, transmittance and kernel value of every entry ----
+    {
+      unsigned h = hits;
+      int k = h ? __builtin_ctz(h) : 0;
+      float4 ge = s.geo[k], vi = s.vin[k];
+#pragma unroll
+      for (int j = 0; j < kStageBwd; ++j) {
+        if (j >= nh) break;  // wave-uniform
+        h &= h - 1;
+        k = h ? __builtin_ctz(h) : 0;
+        const float4 ge_n = s.geo[k], vi_n = s.vin[k];  // next listed entry (entry 0 again after the last: harmless)
+        const bool in = (__float_as_uint(ge.w) & lane_bits) == lane_bits;
+        const float dx = fx - ge.x, dy = fy - ge.y;
+        // (d Λ) d^T (gs_model.py:495) as a dx^2 + (b + c) dx dy + d dy^2
+        const float g = __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy);
+        const float incl = T * (1.0f - ge.z * g);          // gs_model.py:535, inclusive grouped cumprod
+#if GCP_BWD_SAVE_G
+        Tk[j] = T;
+        gk[j] = (in & (incl != 0.0f)) ? g : 0.0f;          // dropped when the inclusive product is exactly 0 (gs_model.py:560)
 #else
-      const float S = gC - acc;
+        Tk[j] = (in & (incl != 0.0f)) ? T : 0.0f;
 #endif
-      const float sa = S * __builtin_amdgcn_rcpf(anti);   // S / anti (v_rcp_f32, 1 ulp)
-      float r_o = keep ? gp * co.w - g * sa : 0.0f;       // gs_model.py:733-740 (gp / o for o != 0)
-      float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;  // true dL/dl (reference: gp / l, Q2)
-      float r_c = keep ? gp - og * sa : 0.0f;       // gs_model.py:747-748, :757-758
-      float r_cx = r_c * dx;
-      float r_xx = r_cx * dx;
-      T = in ? incl : T;
-      // Seven 16-lane row sums by a transposed butterfly: at each step a lane keeps half of its values and hands the
-      // other half to its partner, so the live registers halve.  Partners: 15-i, 7-i (within each half), i^2, i^1;
-      // afterwards lane i holds the row sum of value ((i>>1)&1)*4 + ((i>>2)&1)*2 + ((i>>3)&1) (slot 7 is a dummy).
-      // The first two steps split the lanes by bit 3 and bit 2, i.e. by DPP bank: two bank-masked v_add_f32_dpp
-      // writing one destination do "keep + partner's copy" for both classes without a select (7 + 4 VALU); the last
-      // two need selects (3 + 1).  15 VALU instead of 7 x 4 = 28.
-      {
+        T = in ? incl : T;
+        ge = ge_n; vi = vi_n;
+      }
+    }
+    // ---- pass B: back to front, gradients ----
+    {
+      unsigned h = hits;
+      int k = h ? 31 - __builtin_clz(h) : 0;
+      float4 ge = s.geo[k], co = s.col[k];
+#if !GCP_BWD_SAVE_G
+      float4 vi = s.vin[k];
+#endif
+#pragma unroll
+      for (int j = kStageBwd - 1; j >= 0; --j) {
+        if (j < nh) {  // wave-uniform; the bodies above the list length are skipped once per chunk
+        const int kc = k;
+        h &= ~(1u << kc);
+        k = h ? 31 - __builtin_clz(h) : 0;
+        const float4 ge_n = s.geo[k], co_n = s.col[k];
+        const float dx = fx - ge.x;
+#if GCP_BWD_SAVE_G
+        const float gv = gk[j];
+#else
+        const float4 vi_n = s.vin[k];
+        const float dy = fy - ge.y;
+        const float gv = (Tk[j] != 0.0f) ? __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy) : 0.0f;
+        vi = vi_n;
+#endif
+        const float tg = Tk[j] * gv;
+        const float c = g0 * co.x + g1 * co.y + g2 * co.z;   // dL/dI . l
+        const float d = c - R;
+        float r_o = tg * d;
+        const float wgt = tg * ge.z;                            // T o g (gs_model.py:500 without l)
+        float r_c = wgt * d;
+        float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;
+        float r_cx = r_c * dx;
+        float r_xx = r_cx * dx;
+        R = R + (ge.z * gv) * d;                                // R_{k-1} = R_k + a_k (c_k - R_k)
+        ge = ge_n; co = co_n;
+        // Seven 16-lane row sums by a transposed butterfly: at each step a lane keeps half of its values and hands the
+        // other half to its partner, so the live registers halve.  Partners: 15-i, 7-i (within each half), i^2, i^1;
+        // afterwards lane i holds the row sum of value ((i>>1)&1)*4 + ((i>>2)&1)*2 + ((i>>3)&1) (slot 7 is a dummy).
+        // The first two steps split the lanes by bit 3 and bit 2, i.e. by DPP bank: two bank-masked v_add_f32_dpp
+        // writing one destination do "keep + partner's copy" for both classes without a select (7 + 4 VALU); the last
+        // two need selects (3 + 1).  15 VALU instead of 7 x 4 = 28.
         float q0, q1, q2, q3, p0, p1;
 #if GCP_DPP_ASM
         // s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states
@@ -558,7 +614,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
 #endif
         const float o0 = xchg_sum<0x4e>(b1, p0, p1);
         const float tot = o0 + dpp_f<0xb1, 0xf>(0.0f, o0);
-        row_slot[k * kPartStride] = tot;  // lanes i and i^1 store the same word
+        row_slot[kc * kPartStride] = tot;  // lanes i and i^1 store the same word
+        }
       }
     }
     __syncthreads();
@@ -839,29 +896,36 @@ static int make_args(BlendArgs& a, const int32_t* start_xy, const int32_t* end_x
   return GCP_OK;
 }
 
+size_t gcp_blend_checkpoint_floats(int64_t n_tile_pairs, int32_t width, int32_t height) {
+  if (width < 0 || height < 0) return 0;
+  const TileGrid tg = tile_grid(width, height);
+  return ckpt_floats((i64)n_tile_pairs, tg.tx * tg.ty);
+}
+
 int gcp_blend_forward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy, const float* vinv,
                       const float* opacity, const float* l_d, int64_t n_gauss, int32_t width, int32_t height,
-                      const int32_t* tile_start, const int32_t* tile_list, float* image, void* stream_) {
+                      const int32_t* tile_start, const int32_t* tile_list, float* image, float* t_ckpt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, mean_xy, vinv, opacity, l_d, width, height, tile_start, tile_list);
   if (st != GCP_OK || !image || n_gauss < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n_gauss > 0 && (!start_xy || !end_xy || !mean_xy || !vinv || !opacity || !l_d)) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
-  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, image);
+  if (t_ckpt) hipLaunchKernelGGL((k_blend_fwd<true>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, image, t_ckpt);
+  else hipLaunchKernelGGL((k_blend_fwd<false>), dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, image, (float*)nullptr);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 
 size_t gcp_blend_backward_workspace_bytes(int64_t n_tile_pairs) {
-  // per-entry partial sums, then one 256-byte slot for max |l_d| (the bound of the suffix sums)
-  return align256((size_t)(n_tile_pairs > 0 ? n_tile_pairs : 1) * kGradVals * sizeof(float)) + 256;
+  // per-entry partial sums
+  return align256((size_t)(n_tile_pairs > 0 ? n_tile_pairs : 1) * kGradVals * sizeof(float));
 }
 
 int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy, const float* vinv,
                        const float* opacity, const float* l_d, int64_t n_gauss, int32_t width, int32_t height,
                        const int32_t* tile_off, int64_t n_tile_pairs, const int32_t* tile_start,
-                       const int32_t* tile_list, const float* image, const float* grad_image, float* grad_mean,
+                       const int32_t* tile_list, const float* t_ckpt, const float* grad_image, float* grad_mean,
                        float* grad_vinv, float* grad_opacity, float* grad_l, void* ws, size_t ws_bytes,
                        void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -869,19 +933,15 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
   const int st = make_args(a, start_xy, end_xy, mean_xy, vinv, opacity, l_d, width, height, tile_start, tile_list);
   if (st != GCP_OK || n_gauss < 0 || n_tile_pairs < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n_gauss == 0) return GCP_OK;
-  if (!start_xy || !end_xy || !mean_xy || !vinv || !opacity || !l_d || !tile_off || !image || !grad_image ||
+  if (!start_xy || !end_xy || !mean_xy || !vinv || !opacity || !l_d || !tile_off || !t_ckpt || !grad_image ||
       !grad_mean || !grad_vinv || !grad_opacity || !grad_l || !ws)
     return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_blend_backward_workspace_bytes(n_tile_pairs)) return GCP_ERR_WORKSPACE;
   const TileGrid tg = tile_grid(width, height);
   float* partial = (float*)ws;
   if (n_tile_pairs > 0) {
-    unsigned* lmax = (unsigned*)((char*)ws + gcp_blend_backward_workspace_bytes(n_tile_pairs) - 256);
-    GCP_HIP(hipMemsetAsync(lmax, 0, sizeof(unsigned), stream));
-    const i64 nl = 3 * (i64)n_gauss;
-    hipLaunchKernelGGL(k_abs_max, dim3((unsigned)((nl + 255) / 256 < 256 ? (nl + 255) / 256 : 256)), dim3(256), 0, stream, l_d, nl, lmax);
-    hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, tile_off, image,
-                       grad_image, (const float*)lmax, partial);
+    hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)(tg.tx * tg.ty)), dim3(256), 0, stream, a, tile_off, t_ckpt,
+                       grad_image, partial);
     GCP_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream,

@@ -208,17 +208,20 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
         with torch.no_grad():
             w, h = int(image_width), int(image_height)
             bins = _raster.bin_tiles(startpoint, endpoint, w, h)
-            image = _raster.blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d)
+            image, t_ckpt = _raster.blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d,
+                                                  with_checkpoints=True)
         ctx.bins = bins
-        ctx.save_for_backward(startpoint, endpoint, mean, variance_inverse, opacity, l_d, image)
+        # the reference saves its inputs plus per-chunk (unique_rects, T_min, sizes) and recomputes the M-length pair
+        # arrays in backward (gs_model.py:691, :786-820); here: the inputs plus one transmittance per pixel and 32 list entries
+        ctx.save_for_backward(startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt)
         return image
 
     @staticmethod
     def backward(ctx, pixel_sum_grad):
-        startpoint, endpoint, mean, variance_inverse, opacity, l_d, image = ctx.saved_tensors
+        startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt = ctx.saved_tensors
         with torch.no_grad():
             g_mean, g_vinv, g_op, g_l = _raster.blend_backward(
-                ctx.bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, image, pixel_sum_grad
+                ctx.bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, pixel_sum_grad
             )
         g_mean = g_mean if mean.is_floating_point() else None  # integer means carry no gradient
         return None, None, None, None, g_mean, g_vinv, g_op.reshape(opacity.shape), g_l, None, None

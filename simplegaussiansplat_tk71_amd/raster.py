@@ -49,6 +49,12 @@ class TileBins:
     tile_start: torch.Tensor  # int32[n_tiles+1] first sorted entry of every tile
     tile_list: torch.Tensor   # int32[K] Gaussian ids, tile-major, depth order inside a tile
 
+    @property
+    def tile_capacity(self):
+        """Upper bound of the (tile, Gaussian) entry count that sizes every buffer derived from the bins (== the exact
+        count when the bins were built with the host read of K; the caller's bound in the capture-safe mode)."""
+        return self.n_tile_pairs
+
 
 def bin_tiles(startpoint, endpoint, width, height):
     """startpoint/endpoint: int [N,2] (x,y) inclusive boxes in depth order."""
@@ -98,43 +104,52 @@ def _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d):
     return start, end, mean_f, vinv, op, col
 
 
-def blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d):
-    """-> image f32[(H+1),(W+1),3] (reference layout, gs_model.py:505)."""
+def blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, with_checkpoints=False):
+    """-> image f32[(H+1),(W+1),3] (reference layout, gs_model.py:505); with_checkpoints=True returns
+    (image, t_ckpt), t_ckpt being the per-pixel transmittance checkpoints `blend_backward` restarts from."""
     start, end, mean_f, vinv, op, col = _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d)
     dev = start.device
     lib = _lib.load()
     image = torch.empty(bins.height + 1, bins.width + 1, 3, dtype=torch.float32, device=dev)
+    ckpt = None
+    if with_checkpoints:
+        ckpt = torch.empty(lib.gcp_blend_checkpoint_floats(bins.tile_capacity, bins.width, bins.height), dtype=torch.float32,
+                           device=dev)
     with torch.cuda.device(dev):
         _lib.check(
             lib.gcp_blend_forward(start.data_ptr(), end.data_ptr(), mean_f.data_ptr(), vinv.data_ptr(), op.data_ptr(),
                                   col.data_ptr(), bins.n_gauss, bins.width, bins.height, bins.tile_start.data_ptr(),
-                                  bins.tile_list.data_ptr(), image.data_ptr(), _stream(dev)),
+                                  bins.tile_list.data_ptr(), image.data_ptr(), ckpt.data_ptr() if with_checkpoints else None,
+                                  _stream(dev)),
             "gcp_blend_forward",
         )
-    return image
+    return (image, ckpt) if with_checkpoints else image
 
 
-def blend_backward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, image, grad_image):
-    """-> (grad_mean [N,2], grad_variance_inverse [N,2,2], grad_opacity [N,1], grad_l_d [N,3])."""
+def blend_backward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, grad_image):
+    """-> (grad_mean [N,2], grad_variance_inverse [N,2,2], grad_opacity [N,1], grad_l_d [N,3]).
+    `t_ckpt`: the checkpoints `blend_forward(..., with_checkpoints=True)` returned for the same bins and inputs."""
     start, end, mean_f, vinv, op, col = _params(startpoint, endpoint, mean, variance_inverse, opacity, l_d)
     dev = start.device
     n = bins.n_gauss
-    img = _dev_tensor(image, "image", torch.float32)
     gimg = _dev_tensor(grad_image, "grad_image", torch.float32)
     shape = (bins.height + 1, bins.width + 1, 3)
-    _require(tuple(img.shape) == shape and tuple(gimg.shape) == shape, f"image / grad_image: expected shape {shape}")
+    _require(tuple(gimg.shape) == shape, f"grad_image: expected shape {shape}")
     lib = _lib.load()
+    ck = _dev_tensor(t_ckpt, "t_ckpt", torch.float32)
+    _require(ck.numel() >= lib.gcp_blend_checkpoint_floats(bins.tile_capacity, bins.width, bins.height),
+             "t_ckpt: too small for these bins (pass what blend_forward(..., with_checkpoints=True) returned)")
     g_mean = torch.empty(n, 2, dtype=torch.float32, device=dev)
     g_vinv = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
     g_op = torch.empty(n, 1, dtype=torch.float32, device=dev)
     g_l = torch.empty(n, 3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        ws = torch.empty(lib.gcp_blend_backward_workspace_bytes(bins.n_tile_pairs), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.gcp_blend_backward_workspace_bytes(bins.tile_capacity), dtype=torch.uint8, device=dev)
         _lib.check(
             lib.gcp_blend_backward(start.data_ptr(), end.data_ptr(), mean_f.data_ptr(), vinv.data_ptr(), op.data_ptr(),
                                    col.data_ptr(), n, bins.width, bins.height, bins.tile_off.data_ptr(),
-                                   bins.n_tile_pairs, bins.tile_start.data_ptr(), bins.tile_list.data_ptr(),
-                                   img.data_ptr(), gimg.data_ptr(), g_mean.data_ptr(), g_vinv.data_ptr(),
+                                   bins.tile_capacity, bins.tile_start.data_ptr(), bins.tile_list.data_ptr(),
+                                   ck.data_ptr(), gimg.data_ptr(), g_mean.data_ptr(), g_vinv.data_ptr(),
                                    g_op.data_ptr(), g_l.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
             "gcp_blend_backward",
         )

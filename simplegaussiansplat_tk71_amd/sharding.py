@@ -180,10 +180,10 @@ def _hip_blend(s, e, m, variance_inverse, opacity, l_d, width, height, grad_band
     from . import raster
 
     bins = raster.bin_tiles(s, e, width, height)
-    img = raster.blend_forward(bins, s, e, m, variance_inverse, opacity, l_d)
     if grad_band is None:
-        return img, None
-    g_mean, g_vinv, g_op, g_l = raster.blend_backward(bins, s, e, m, variance_inverse, opacity, l_d, img, grad_band)
+        return raster.blend_forward(bins, s, e, m, variance_inverse, opacity, l_d), None
+    img, ckpt = raster.blend_forward(bins, s, e, m, variance_inverse, opacity, l_d, with_checkpoints=True)
+    g_mean, g_vinv, g_op, g_l = raster.blend_backward(bins, s, e, m, variance_inverse, opacity, l_d, ckpt, grad_band)
     return img, (g_vinv, g_op, g_l)
 
 

@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_hip_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.gcp_abi_version() == _lib.ABI_VERSION == 1
+    assert lib.gcp_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -106,10 +106,12 @@ def test_raster_argument_validation_needs_no_gpu():
     assert lib.gcp_tile_grid(-1, 5, ctypes.byref(tx), ctypes.byref(ty)) == 1
     assert lib.gcp_bin_workspace_bytes(1000, 3000) % 256 == 0
     assert lib.gcp_bin_workspace_bytes(1_000_000, 3_000_000) < 64 << 20
-    assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4 + 256  # 9 floats per (tile, Gaussian) entry + one slot
+    assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4  # 9 floats per (tile, Gaussian) entry
+    # one transmittance per pixel of a tile per 32 list entries: K / 32 + n_tiles + 1 slots of 256 floats
+    assert lib.gcp_blend_checkpoint_floats(3_000_000, 1919, 1079) == (3_000_000 // 32 + 120 * 68 + 1) * 256
     k = ctypes.c_int64(-1)
     assert lib.gcp_bin_tiles_count(None, None, -1, 10, 10, None, ctypes.byref(k), None, 0, None) == 1
-    assert lib.gcp_blend_forward(None, None, None, None, None, None, 5, 10, 10, None, None, None, None) == 1
+    assert lib.gcp_blend_forward(None, None, None, None, None, None, 5, 10, 10, None, None, None, None, None) == 1
     assert lib.gcp_exclusive_scan_i32(None, None, 5, None, 0, None) == 1
 
 

@@ -69,15 +69,6 @@ def test_function_vs_dense_oracle(device, n_gauss, w, h, mh, seed, one):
     if one:
         assert bool((sc["opacity"] == 1.0).any())
     torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
-    # The backward walks a pixel's list front to back and forms the suffix sum of (g . p) as total - prefix
-    # (DESIGN.md §7 f1): behind ~800 layers the prefix carries ~depth * 2^-24 * |total| of fp32 round-off, which shows
-    # up as absolute noise of a few 1e-5 on gradients whose true value is ~0 (times dx^2 <= 24^2 in the second moments
-    # behind grad_vinv).  The image is unaffected.
-    if n_gauss == 900:  # stated bound of the deep case: 1e-5 of the largest gradient component + 5e-5 absolute
-        for got, want, what in ((go, go64, "grad_opacity"), (gv, gv64, "grad_vinv"), (gl, gl64, "grad_l")):
-            err = (got.double().cpu() - want.double()).abs().max().item()
-            assert err <= TOL * want.abs().max().item() + 5e-5, (what, err, want.abs().max().item())
-        return
     _close(go, go64, go64.abs().mean().item(), "grad_opacity")
     _close(gv, gv64, gv64.abs().mean().item(), "grad_vinv")
     _close(gl, gl64, gl64.abs().mean().item(), "grad_l")
@@ -192,15 +183,15 @@ def test_band_sharded_blend_equals_full_frame(device):
     d = {k: v.to(device) for k, v in sc.items() if isinstance(v, torch.Tensor)}
     w, h = 130, 100
     full_bins = raster.bin_tiles(d["start"], d["end"], w, h)
-    full = raster.blend_forward(full_bins, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"])
-    gfull = raster.blend_backward(full_bins, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], full, d["wimg"])
+    full, fck = raster.blend_forward(full_bins, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], with_checkpoints=True)
+    gfull = raster.blend_backward(full_bins, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], fck, d["wimg"])
     acc = None
     rows = []
     for band in sharding.row_bands(h, 3):
         s, e, m, bh = sharding.band_view(d["start"], d["end"], d["mean"], band)
         bins = raster.bin_tiles(s, e, w, bh)
-        img = raster.blend_forward(bins, s, e, m, d["vinv"], d["opacity"], d["l_d"])
-        g = raster.blend_backward(bins, s, e, m, d["vinv"], d["opacity"], d["l_d"], img, d["wimg"][band[0] : band[1] + 1].contiguous())
+        img, ck = raster.blend_forward(bins, s, e, m, d["vinv"], d["opacity"], d["l_d"], with_checkpoints=True)
+        g = raster.blend_backward(bins, s, e, m, d["vinv"], d["opacity"], d["l_d"], ck, d["wimg"][band[0] : band[1] + 1].contiguous())
         rows.append(img)
         acc = g if acc is None else tuple(a + b for a, b in zip(acc, g))
     assert torch.equal(torch.cat(rows, 0), full)
@@ -338,9 +329,9 @@ def test_all_boxes_empty(device):
     assert bins.n_tile_pairs == 0
     args = (start, end, start.float(), torch.eye(2, device=device).repeat(n, 1, 1), torch.full((n, 1), 0.5, device=device),
             torch.ones(n, 3, device=device))
-    img = raster.blend_forward(bins, *args)
+    img, ck = raster.blend_forward(bins, *args, with_checkpoints=True)
     assert float(img.abs().sum()) == 0.0
-    grads = raster.blend_backward(bins, *args, img, torch.ones_like(img))
+    grads = raster.blend_backward(bins, *args, ck, torch.ones_like(img))
     assert all(float(g.abs().sum()) == 0.0 for g in grads)
 
 
@@ -375,11 +366,12 @@ def test_render_cameras_on_two_streams_equals_sequential(device):
         assert torch.equal(a, b)
 
 
-def test_gaussians_behind_an_opaque_stack_get_transmittance_sized_gradients(device):
-    """The backward forms a pixel's suffix sums as total - prefix; the prefix's fp32 round-off (~1e-7 of the total) would
-    otherwise be the gradient of every Gaussian behind an opaque stack — pure noise that Adam normalises into full-size
-    steps.  The suffix is clamped to its analytic bound T * sum|g| * max|l| (include/grouped_cumprod_hip.h), so such
-    gradients are of the size of the transmittance, as in the reference's reverse scan."""
+def test_gaussians_behind_an_opaque_stack_get_accurate_gradients(device):
+    """60 layers of opacity 0.6 over the whole image leave T ~ 1e-24 for the 40 Gaussians behind them.  The reference's
+    reverse scan (gs_model.py:716-722) gives those their true, tiny gradients; a backward that forms suffix sums as
+    (pixel total) - (prefix) hands them ~1e-7 of the total instead — noise that Adam normalises into full-size steps.
+    Here every gradient term is T_k times a bounded quantity (csrc/gcp_raster.hip, k_blend_bwd), so the hidden
+    Gaussians' gradients must be right to a RELATIVE 1e-3 although they are ~1e-20."""
     w = h = 31
     n_front, n_back = 60, 40
     n = n_front + n_back
@@ -400,10 +392,73 @@ def test_gaussians_behind_an_opaque_stack_get_transmittance_sized_gradients(devi
     for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
         hidden_true = want[n_front:].abs().max().item()
         assert hidden_true < 1e-8, (name, hidden_true)                   # far below the ~1e-6 round-off of the pixel totals
-        hidden_got = got[n_front:].abs().max().item()
-        assert hidden_got <= 100 * hidden_true, (name, hidden_got, hidden_true)  # ... and of that size here too (the bound,
-        # not the exact suffix, is what the clamp guarantees)
-        assert want[:n_front].abs().max().item() > 1e-3, name               # the visible ones still learn
+        assert want[:n_front].abs().max().item() > 1e-3, name              # the visible ones still learn
+        # per Gaussian: error relative to that Gaussian's own gradient magnitude (sum of |components|), hidden ones included
+        got, want = got.double().reshape(n, -1), want.reshape(n, -1)
+        rel = (got - want).abs().sum(1) / want.abs().sum(1).clamp(min=1e-300)
+        assert float(rel.max()) < 1e-3, (name, float(rel.max()), int(rel.argmax()))
+
+
+def _stack_scene(n_layers, opacity_lo, opacity_hi, seed, w=15, h=15):
+    """`n_layers` wide Gaussians over one 16x16 tile: every pixel's list is n_layers deep."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_layers
+    start = torch.zeros(n, 2, dtype=torch.int32)
+    end = torch.tensor([[w, h]], dtype=torch.int32).repeat(n, 1)
+    mean = torch.randint(2, 14, (n, 2), generator=g).to(torch.int32)
+    sx = 4.0 + 8.0 * torch.rand(n, generator=g)
+    vinv = torch.zeros(n, 2, 2)
+    vinv[:, 0, 0] = 1.0 / (sx * sx)
+    vinv[:, 1, 1] = 1.0 / (sx * sx)
+    opacity = opacity_lo + (opacity_hi - opacity_lo) * torch.rand(n, 1, generator=g)
+    return {"start": start, "end": end, "mean": mean, "vinv": vinv, "opacity": opacity, "l_d": 0.1 + torch.rand(n, 3, generator=g),
+            "boxsize": torch.prod((end - start + 1).long(), 1), "width": w, "height": h,
+            "wimg": torch.randn(h + 1, w + 1, 3, generator=g)}
+
+
+@pytest.mark.parametrize("n_layers,op_lo,op_hi", [(4096, 0.0005, 0.004), (4096, 0.002, 0.02), (1200, 0.005, 0.05)])
+def test_deep_pixel_columns_relative_gradient_accuracy(device, n_layers, op_lo, op_hi):
+    """Pixel lists as deep as BASELINE's configs allow (4096 layers: 128 backward chunks, 16 forward staging rounds),
+    with opacities chosen so that the transmittance falls through [1, 1e-2 .. 1e-20] along the list.  Every Gaussian's
+    gradient must be accurate RELATIVE to its own size — the semi-occluded ones (T in [1e-5, 1e-2]) are exactly where a
+    total-minus-prefix backward loses all digits — against the dense fp64 renderer."""
+    from oracle import dense_render as dr
+
+    sc = _stack_scene(n_layers, op_lo, op_hi, seed=n_layers + int(op_hi * 1e4))
+    img, gv, go, gl = _apply(device, sc)
+    i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"],
+                                                 sc["width"], sc["height"], sc["wimg"])
+    torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    # Every box covers the whole image, so the per-(Gaussian, pixel) terms have a closed dense form (fp64): with them
+    # the CONDITION SCALE of every gradient — the sum over pixels of the |terms| whose signed sum it is — is known, and
+    # the bound can be stated relative to the Gaussian's own terms instead of the scene's largest gradient.
+    n, w, h = n_layers, sc["width"], sc["height"]
+    ys, xs = torch.meshgrid(torch.arange(h + 1, dtype=torch.float64), torch.arange(w + 1, dtype=torch.float64), indexing="ij")
+    dx = xs.reshape(1, -1) - sc["mean"][:, 0:1].double()
+    dy = ys.reshape(1, -1) - sc["mean"][:, 1:2].double()
+    v = sc["vinv"].double()
+    gk = torch.exp(-0.5 * (dx * dx * v[:, 0, 0, None] + dx * dy * (v[:, 0, 1, None] + v[:, 1, 0, None]) + dy * dy * v[:, 1, 1, None]))
+    a = sc["opacity"].double() * gk                                                   # [n, P]
+    T = torch.cumprod(torch.cat([torch.ones(1, a.size(1), dtype=torch.float64), 1.0 - a[:-1]]), 0)   # exclusive
+    c = sc["l_d"].double() @ sc["wimg"].double().reshape(-1, 3).T                      # dL/dI . l   [n, P]
+    S = torch.flip(torch.cumsum(torch.flip(T * a * c, [0]), 0), [0]) - T * a * c       # exclusive suffix sums
+    sa = S / (1.0 - a)
+    abs_o = (T * gk * c.abs() + gk * sa.abs()).sum(1)                                  # scale of dL/do (gs_model.py:733-740)
+    abs_c = T * a * c.abs() + a * sa.abs()                                             # scale of the "common" factor
+    abs_l = (T * a)[:, :, None] * sc["wimg"].double().reshape(1, -1, 3).abs()          # [n, P, 3]
+    scales = {"opacity": abs_o[:, None], "l_d": abs_l.sum(1),
+              "vinv": 0.5 * torch.stack([(abs_c * dx * dx).sum(1), (abs_c * (dx * dy).abs()).sum(1), (abs_c * (dx * dy).abs()).sum(1),
+                                         (abs_c * dy * dy).sum(1)], 1)}
+    assert float((T[:, 120] < 1e-2).double().mean()) > 0.3 and float(T[-1, 120]) < 1e-3    # the list really runs into occlusion
+    seen = {}
+    for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
+        got, want, scale = got.double().reshape(n, -1), want.reshape(n, -1), scales[name]
+        err = (got - want).abs()
+        bound = 2e-5 * scale + 1e-30
+        assert bool((err <= bound).all()), (name, float((err / (scale + 1e-300)).max()), int((err > bound).any(1).nonzero()[0]))
+        seen[name] = (float(scale.max()), float(scale.min()), float((err / (scale + 1e-300)).max()))
+    print(f"{n_layers} layers, opacity [{op_lo}, {op_hi}], T at the list end {float(T[-1, 120]):.1e}: per-Gaussian (largest "
+          f"condition scale, smallest, max err / scale): {seen}")
 
 
 def test_random_small_scenes_against_the_dense_oracle(device):
@@ -422,10 +477,7 @@ def test_random_small_scenes_against_the_dense_oracle(device):
         i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"], w, h, sc["wimg"])
         what = f"case {case}: {n} Gaussians, {w}x{h}, half <= {mh}"
         torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL, msg=lambda m: f"{what}: {m}")
-        # the single-traversal suffix sums carry ~depth * 2^-24 of a pixel's total, times dx^2 (up to
-        # 40^2 here) in the second moments behind grad_vinv: bounds relative to the largest component of each gradient,
-        # 1e-5 up to ~100 layers and 4e-5 for the 300-layer stacks some of these scenes are
-        tol = TOL if n <= 129 else 4 * TOL
-        _close(go, go64, go64.abs().max().item(), what + " grad_opacity", tol)
-        _close(gv, gv64, gv64.abs().max().item(), what + " grad_vinv", tol)
-        _close(gl, gl64, gl64.abs().max().item(), what + " grad_l", tol)
+        # one bound for every depth (1 to 300 layers per pixel here): 1e-5 relative to the mean gradient component
+        _close(go, go64, go64.abs().mean().item(), what + " grad_opacity")
+        _close(gv, gv64, gv64.abs().mean().item(), what + " grad_vinv")
+        _close(gl, gl64, gl64.abs().mean().item(), what + " grad_l")

@@ -28,6 +28,7 @@ def timeit(fn, iters=10, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-cameras", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     sc = synthetic.make_scene_config(args.config, seed=0, device=dev)
@@ -39,21 +40,22 @@ def main():
     torch.cuda.synchronize()
     print(f"tile pairs K={bins.n_tile_pairs} ({bins.n_tile_pairs/n:.2f} per Gaussian), tiles {bins.tiles_x}x{bins.tiles_y}, first bin {time.time()-t0:.3f}s")
     args_ = (sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"])
-    img = raster.blend_forward(bins, *args_)
+    img, ck = raster.blend_forward(bins, *args_, with_checkpoints=True)
     gimg = torch.randn_like(img)
     res = {
         "bin_tiles": timeit(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h)),
-        "blend_forward": timeit(lambda: raster.blend_forward(bins, *args_)),
-        "blend_backward": timeit(lambda: raster.blend_backward(bins, *args_, img, gimg)),
+        "blend_forward (image only)": timeit(lambda: raster.blend_forward(bins, *args_)),
+        "blend_forward": timeit(lambda: raster.blend_forward(bins, *args_, with_checkpoints=True)),
+        "blend_backward": timeit(lambda: raster.blend_backward(bins, *args_, ck, gimg)),
     }
     tot = 0.0
     for k, (med, mn) in res.items():
-        tot += med
-        print(f"{k:16s} median {med*1e3:9.1f} us  min {mn*1e3:9.1f} us   {m/med/1e6:8.2f} Gpairs/s")
+        tot += med if "only" not in k else 0.0
+        print(f"{k:28s} median {med*1e3:9.1f} us  min {mn*1e3:9.1f} us   {m/med/1e6:8.2f} Gpairs/s")
     print(f"bin+fwd+bwd {tot*1e3:.1f} us -> {m/tot/1e6:.2f} Gpairs/s end to end (whole Function)")
     # a batch of cameras (the reference renders them one after the other, gs_model.py:402-449): 1 vs 2 streams
     cams = [sc] * 6
-    for ns in (1, 2, 3):
+    for ns in (() if args.no_cameras else (1, 2, 3)):
         t, _ = timeit(lambda: raster.render_cameras(cams, n_streams=ns), iters=5, warmup=2)
         print(f"render 6 cameras (bin + forward) on {ns} stream(s): {t:.3f} ms")
 

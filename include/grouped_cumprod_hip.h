@@ -29,15 +29,15 @@
  *   - every function returns GCP_OK (0) or a GCP_ERR_* code; n == 0 is a no-op;
  *   - results are deterministic run to run (no value-carrying atomics).
  *
- * Workspace: the scans are single-pass for realistic inputs; groups longer than
- * one tile's look-back window use a per-tile descriptor fallback that needs
- * gcp_workspace_bytes(n) bytes of scratch.  Pass ws == NULL to let the library
- * use an internal per-device scratch buffer (grown with hipMalloc on demand —
- * not graph-capturable, and not safe for concurrent launches on two streams).
- * A caller-provided workspace needs no initialisation (the fallback is stateless;
- * gcp_workspace_init() is kept for ABI stability and only clears the
- * introspection counter) and may be reused by any number of calls that are
- * ordered on one stream.
+ * Workspace: the scans are single-pass.  A group longer than one tile's raw look-back window (4096 elements)
+ * continues on per-tile descriptors inside the same launch; a tile that would have to wait too long for another
+ * tile's descriptor is finished by a small follow-up launch (a no-op otherwise).  Both need
+ * gcp_workspace_bytes(n) bytes of scratch (0.4 % of one array).  Pass ws == NULL to let the library use an internal
+ * per-device scratch buffer (grown with hipMalloc on demand — not graph-capturable, and not safe for concurrent
+ * launches on two streams).  A caller-provided workspace must be zeroed ONCE before its first use
+ * (gcp_workspace_init, or any memset of the whole buffer): it carries a launch counter and two descriptor sets used
+ * alternately, each launch clearing the set the next one will publish into.  After that it may be reused by any
+ * number of calls of any size that fits, as long as they are ORDERED on one stream (or otherwise never overlap).
  */
 #ifndef GROUPED_CUMPROD_HIP_H
 #define GROUPED_CUMPROD_HIP_H
@@ -72,7 +72,7 @@ const char* gcp_status_string(int status);
 /* Bytes of scratch needed for arrays of n elements (multiple of 256). */
 size_t gcp_workspace_bytes(int64_t n);
 
-/* Zero the control words of a caller-provided workspace (async on `stream`). */
+/* Zero a caller-provided workspace (async on `stream`); required once before its first use. */
 int gcp_workspace_init(void* ws, size_t ws_bytes, void* stream);
 
 /*
@@ -153,10 +153,18 @@ int gcp_check_groups(const int32_t* inv, const int32_t* inv_len, int64_t n,
 /* Tuning / introspection (used by bench.py and the tests). */
 /* Elements per scan tile of the loaded build. */
 int gcp_tile_elems(void);
-/* Number of tiles the most recent scan on this host thread's workspace `ws`
- * could not resolve by look-back and fixed up through the descriptor path
+/* Number of tiles the most recent scan on workspace `ws` could not resolve inside the main launch (their wait for
+ * another tile's descriptor ran out) and that the follow-up launch fixed up
  * (synchronises `stream`; ws == NULL selects the internal workspace). */
 int gcp_last_fallback_tiles(void* ws, void* stream, int64_t* n_tiles);
+/* Longest time (microseconds) a tile waits for another tile's descriptor before it leaves its carry to the
+ * follow-up launch; default 200 (environment GCP_DESC_WAIT_US).  0 = look once, never wait; negative = skip the
+ * descriptor walk altogether (every group that starts more than one tile back goes to the follow-up launch — the
+ * two-pass behaviour, kept for tests and A/B timing).  Process-wide; results are identical for every setting. */
+int gcp_set_lookback_wait_us(int64_t us);
+/* Number of tiles of that scan whose group started more than one tile back and that resolved their carry through
+ * the descriptor look-back inside the main launch. */
+int gcp_last_lookback_tiles(void* ws, void* stream, int64_t* n_tiles);
 
 
 /* ------------------------------------------------------------------------------------------

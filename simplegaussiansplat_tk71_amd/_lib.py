@@ -36,6 +36,8 @@ SIGNATURES = {
     "gcp_check_groups": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, ctypes.POINTER(_i64), _c_void_p]),
     "gcp_tile_elems": (ctypes.c_int, []),
     "gcp_last_fallback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
+    "gcp_last_lookback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
+    "gcp_set_lookback_wait_us": (ctypes.c_int, [_i64]),
     # rows f1 / f2 (gcp_raster.hip)
     "gcp_tile_grid": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "gcp_scan_i32_workspace_bytes": (_sz, [_i64]),

@@ -19,16 +19,25 @@
 //     waves through 4 LDS words and ONE barrier.
 //   * No inter-block communication on the common path: the carry entering a
 //     tile is recomputed by wave 0 from the raw inputs with a bounded look-back
-//     (LB_CHUNKS x 256 elements; those bytes are L2/MALL-resident because the
-//     neighbouring tile is being streamed at the same time).  Groups that reach
-//     further back than the window are rare for per-pixel splat lists; they are
-//     handled exactly by a descriptor fallback: every tile stores {aggregate,
-//     open, unresolved, first head offset} (8 B / tile); ONE follow-up kernel
-//     (<= 256 blocks, each owning a contiguous range of tiles) returns at once
-//     when its range holds no unresolved tile, and otherwise scans the
-//     descriptors and folds the missing prefix into the leading elements of the
-//     unresolved tiles.  Stateless, no spinning, no value-carrying atomics:
-//     deterministic, and the workspace needs no initialisation.
+//     (LB_CHUNKS x 256 elements = one tile; those bytes are L2/MALL-resident
+//     because the neighbouring tile is being streamed at the same time).
+//   * Groups that reach further back than that window (pixel lists > 4096 deep)
+//     continue IN THE SAME PASS on per-tile descriptors: every tile publishes
+//     {aggregate of its trailing group, open/closed, first head offset} as one
+//     64-bit word (agent-scope store) as soon as its local scan is done; a tile
+//     whose raw window is exhausted walks the descriptors of the tiles before it,
+//     64 per step, multiplying the aggregates of head-less ("open") tiles until it
+//     meets a tile with a head or with an already resolved prefix.  Waiting for a
+//     descriptor that is not published yet is BOUNDED (wall clock): a tile that
+//     runs out of patience marks itself unresolved and ONE follow-up kernel
+//     (<= 256 blocks, each owning a contiguous range of tiles; a no-op when nothing
+//     is unresolved) folds the missing prefix into its leading elements.  So the
+//     protocol needs no forward-progress or dispatch-order assumption, cannot
+//     hang, and no value-carrying atomic decides a result: deterministic.
+//     Descriptors live in two sets used alternately (parity of a device-side
+//     launch counter); the follow-up kernel of one launch clears the set the next
+//     launch will use, so a stale word is never taken for a published one.  The
+//     workspace must be zeroed once (gcp_workspace_init).
 //   * The backward (a3) is the same machinery run in reverse index order on
 //     w[i] = grad_out[i] * cumprod[i] with the division by p'_j fused into the
 //     store: one O(n) pass, 20 B / element.
@@ -39,6 +48,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 
 #include "gcp_device.hpp"
@@ -77,8 +87,29 @@ constexpr int kLbBatch = GCP_LB_BATCH;  // look-back chunks fetched per dependen
 constexpr int kLbChunks = ((kTile / 256 - 1) / kLbBatch) * kLbBatch + 1;  // window in 256-element chunks (16 = one tile at kRows 4)
 constexpr int kFixBlocks = 256;     // upper bound of the fallback kernel's grid
 constexpr int kWsHeaderBytes = 256;
+// workspace header words
+constexpr int kHdrEpoch = 0;        // launches completed on this workspace; its parity selects the descriptor set
+constexpr int kHdrDone = 1;         // fallback blocks finished (the last one advances the epoch)
+constexpr int kHdrUnresolved = 2;   // tiles the fallback kernel fixed up in the last launch (introspection)
+constexpr int kHdrTiles = 3;        // [3], [4]: tiles written in descriptor set 0 / 1 by its last user
+constexpr int kHdrDescResolved = 5; // tiles that took their carry from the block tree in the last launch (introspection;
+                                    // counted by the follow-up kernel from a flag in the level-0 descriptors: one atomic per
+                                    // tile inside the main kernel serialises at the L2 and cost 1 ms per 40 000 tiles)
+// descriptor = {aggregate bits (low word), flags (high word)}
+constexpr unsigned kDOpen = 1u;        // the aggregate is relative to the tile's (still unknown) carry-in: no head in the tile
+constexpr unsigned kDUnresolved = 2u;  // the tile's leading elements still lack their carry (the fallback kernel's work list)
+constexpr unsigned kDValid = 1u << 15; // published in this launch (the set was cleared before)
+constexpr unsigned kDTree = 1u << 16;  // the tile took its carry from the block tree (introspection; level 0 only)
+#ifndef GCP_XCD_CHUNK
+#define GCP_XCD_CHUNK 32
+#endif
+constexpr int kLevels = 4;          // radix-64 block tree over the tiles: 64^4 tiles = 6.9e10 elements
+constexpr int kXcdChunk = GCP_XCD_CHUNK;  // consecutive tiles one XCD takes before the next XCD's run starts
+#ifndef GCP_DESC_WAIT_US
+#define GCP_DESC_WAIT_US 200
+#endif
 
-static_assert(kLbChunks * 256 <= kTile, "look-back window must fit in one tile");
+static_assert(kLbChunks * 256 == kTile, "the raw look-back window is exactly the previous tile (the descriptor walk starts at the tile before it)");
 static_assert((kLbChunks - 1) % kLbBatch == 0, "chunks after the first are fetched kLbBatch at a time");
 
 template <int MODE>
@@ -103,9 +134,12 @@ struct ScanArgs {
   float* out;
   i64 n;
   i64 ntiles;
-  uint2* desc;        // per logical tile: {aggregate bits, open | unresolved<<1 | first_head<<2}
-  unsigned* hdr;      // [2] = unresolved tiles of the last launch (introspection only)
+  unsigned long long* desc_sets;  // two interleaved sets (word 2 e + s) of descriptor entries {aggregate bits, flags |
+                                  // first_head << 2}; entry e = tile t at level 0, then the upper levels of the block tree
+  i64 lvl_off[kLevels + 1];       // first entry of every level of the radix-64 block tree; [kLevels] = entries in all
+  unsigned* hdr;      // workspace header (kHdr*)
   int xcd_remap;
+  long long patience; // longest wait for a missing descriptor, in 100 MHz ticks; < 0: no descriptor walk at all
 };
 
 // Inclusive segmented scan of one value per lane.  `h` = nearest lane <= this
@@ -210,14 +244,23 @@ template <bool REV> __device__ __forceinline__ int4_t to_scan_order(int4_t v) {
   return r;
 }
 
-// Logical (scan-order) tile index of this block.  Blocks are dealt round-robin
-// over the 8 XCDs, so giving blocks b, b+8, b+16, ... consecutive tiles keeps a
-// tile and its look-back source on one XCD's L2.  Performance only.
+// Logical (scan-order) tile index of this block.  Blocks are dealt round-robin over the 8 XCDs; block b runs on XCD
+// b & 7.  Tiles are handed out in groups of 8 * kXcdChunk: inside a group XCD x takes kXcdChunk CONSECUTIVE tiles
+// (blocks x, x+8, x+16, ...), so a tile and its look-back source share an XCD's L2 for all but one tile in
+// kXcdChunk, while the tile before any tile is at most 8 * kXcdChunk blocks away in dispatch order — resident at the
+// same time, which is what keeps the descriptor look-back's waits short.  Performance only: nothing depends on where
+// or when a block runs.
 __device__ __forceinline__ i64 logical_tile(i64 b, i64 ntiles, int xcd_remap) {
   if (!xcd_remap) return b;
-  const i64 q = ntiles >> 3, rem = ntiles & 7;
-  const i64 x = b & 7;
-  return x * q + (x < rem ? x : rem) + (b >> 3);
+  constexpr i64 G = 8 * kXcdChunk;
+  const i64 full = (ntiles / G) * G;
+  if (b >= full) return b;  // the last, partial group keeps dispatch order
+  const i64 g = b / G, r = b - g * G;
+  return g * G + (r & 7) * kXcdChunk + (r >> 3);
+}
+
+__device__ __forceinline__ unsigned long long pack_desc(float agg, unsigned flags, int first_head) {
+  return ((unsigned long long)(flags | kDValid | ((unsigned)first_head << 2)) << 32) | __builtin_bit_cast(unsigned, agg);
 }
 
 // ----------------------------------------------------------------------------
@@ -238,6 +281,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   const i64 n = a.n;
   const i64 pt = REV ? (a.ntiles - 1 - lt) : lt;
   const i64 base = pt * (i64)kTile;
+  // descriptor set of this launch (parity of the workspace's launch counter); a scalar load issued first
+  unsigned long long* const desc = a.desc_sets + (a.hdr[kHdrEpoch] & 1u);  // tile t at desc[2 t]
 
   // ---- issue all loads of this lane ------------------------------------
   // Streaming (non-temporal) loads are faster for bytes nobody reads again, but the END of a tile (scan
@@ -447,25 +492,145 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
           if (!done) done = process(cv[c], ck[c], cp[c], j + c);
         }
       }
-      if (!done) { unresolved = 1; tc = id; }  // the fix-up kernel folds the true prefix in later
+      // window exhausted: the whole tile before this one belongs to the group; tc is its product and the search goes on
+      // on the tile descriptors after the barrier
+      if (!done) unresolved = 1;
       if constexpr (CARRY) {
         // group start found behind the tile (first element is not a head): its carry belongs to the prefix
         const bool first_is_head = nb_exists ? (nbk != k0) : true;
         if (done && !first_is_head) tc = M::op(a.carry[k0], tc);
       }
     }
-    if (lane == 0) { s_tc[0] = tc; s_wf[kWaves] = unresolved; }
+    // [kWaves]: the raw window was exhausted (never rewritten: every wave branches on it after the barrier);
+    // [kWaves + 1]: the carry is still unknown (cleared by the descriptor walk when it succeeds)
+    if (lane == 0) { s_tc[0] = tc; s_wf[kWaves] = unresolved; s_wf[kWaves + 1] = unresolved; }
   }
   __syncthreads();
 
+  // ---- tile descriptors: the canonical radix-64 block tree ------------------------------
+  // Level L, index i holds the segmented aggregate of tiles [i 64^L, (i+1) 64^L): {has a head, aggregate of the
+  // trailing group}.  Tile t publishes level 0, and level L >= 1 when it is the LAST tile of a level-L block.  Every
+  // value in the tree is a fixed-association function of the level-0 entries, so whoever needs the prefix entering
+  // tile t — per level, the up to 63 blocks between the enclosing block's start and t, nearest first, until one holds a
+  // head — gets the same bits in every run, whatever the timing: deterministic, and a chain of at most kLevels
+  // publish-then-read hops behind the neighbours' local scans.
+  //   * a tile that holds a head (the usual case) publishes {head, trailing aggregate} to all its levels at once:
+  //     nothing read, and 1.016 stores per tile on average;
+  //   * a tile without a head (a group longer than the tile) that ends a block reads the block's other 63 children first;
+  //   * a tile whose raw window did not reach the start of its group takes its carry from the tree.
+  // Both waits are bounded (a.patience); what times out is left to the follow-up kernel.
+  // (first_head: elements [0, first_head) of the tile, scan order, take the carry-in; agg: aggregate of the tile's trailing
+  // group relative to an identity carry-in — both only where a descriptor is written)
+  auto tile_summary = [&](int& first_head, float& agg) {
+    first_head = kTile;
+    agg = id;
+#pragma unroll
+    for (int j = kWaves - 1; j >= 0; --j)
+      if (s_wf[j]) first_head = j * WT + s_fh[j];
+#pragma unroll
+    for (int j = 0; j < kWaves; ++j) agg = s_wf[j] ? s_wv[j] : M::op(agg, s_wv[j]);
+  };
+  const bool has_head = (s_wf[0] | s_wf[1] | s_wf[2] | s_wf[3]) != 0;
+  static_assert(kWaves == 4, "has_head reads four wave flags");
+  // levels whose block ends with this tile: 1 .. zl (trailing base-64 digits equal to 63)
+  int zl = 0;
+  while (zl < kLevels - 1 && ((lt >> (6 * zl)) & 63) == 63) ++zl;
+  auto entry = [&](int level, i64 idx) -> unsigned long long* { return desc + 2 * (a.lvl_off[level] + idx); };
+  const bool need_carry = s_wf[kWaves] != 0;
+  if (a.ntiles > 1 && (need_carry || (!has_head && zl > 0))) {  // block-uniform, rare
+    if (w == 0) {
+      int first_head;
+      float agg;
+      tile_summary(first_head, agg);
+      // level 0 first: the tiles behind need it whatever this tile is still waiting for
+      if (lane == 0)
+        __hip_atomic_store(entry(0, lt), pack_desc(agg, has_head ? 0u : kDOpen, first_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (has_head && lane >= 1 && lane <= zl)
+        __hip_atomic_store(entry(lane, lt >> (6 * lane)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // lane i at level L looks at block (t >> 6L) - 1 - i of that level, for i < digit L of t: the blocks between the
+      // start of the enclosing level-(L+1) block and this tile, nearest first
+      int pub_level = has_head ? zl : 0;  // levels 1 .. pub_level are published
+      bool resolved = !need_carry;
+      float tc = id;          // the carry (need_carry)
+      float cur = agg;        // this tile's own block at the level being published (no head so far)
+      bool cur_closed = false;
+      if (a.patience >= 0) {
+        const unsigned long long t0 = wall_clock64();
+        float acc = id;       // head-less blocks gathered so far, levels below `lv`
+        int lv = 0;           // level the carry search has reached
+        while (true) {
+          unsigned long long d[kLevels];
+#pragma unroll
+          for (int L = 0; L < kLevels; ++L) {
+            const i64 self = lt >> (6 * L);
+            d[L] = 0ull;
+            if (lane < (int)(self & 63)) d[L] = __hip_atomic_load(entry(L, self - 1 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int L = 0; L < kLevels; ++L) {
+            const int digit = (int)((lt >> (6 * L)) & 63);
+            const unsigned fl = (unsigned)(d[L] >> 32);
+            const float val = __builtin_bit_cast(float, (unsigned)d[L]);
+            const bool act = lane < digit;
+            const unsigned long long am = digit ? ((1ull << digit) - 1ull) : 0ull;
+            const unsigned long long vm = __ballot(act && (fl & kDValid) != 0u);
+            const unsigned long long cm = __ballot(act && (fl & kDValid) != 0u && (fl & kDOpen) == 0u);
+            const int lf = cm ? __builtin_ctzll(cm) : 63;
+            const unsigned long long want = am & ((lf >= 63) ? ~0ull : ((2ull << lf) - 1ull));  // up to the nearest head
+            const bool ready = (vm & want) == want;
+            // publish level L+1 (this tile ends that block and holds no head): its 63 other children are this level's lanes
+            if (L == pub_level && L < zl && ready) {
+              if (!cur_closed) cur = M::op(wave_reduce<MD::kMul>(((want >> lane) & 1ull) ? val : id), cur);
+              cur_closed = cur_closed || cm != 0ull;
+              if (lane == 0)
+                __hip_atomic_store(entry(L + 1, lt >> (6 * (L + 1))), pack_desc(cur, cur_closed ? 0u : kDOpen, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              pub_level = L + 1;
+            }
+            // the carry: level by level, nearest blocks first
+            if (!resolved && L == lv && ready) {
+              acc = M::op(wave_reduce<MD::kMul>(((want >> lane) & 1ull) ? val : id), acc);  // older blocks on the left
+              if (cm != 0ull || (lt >> (6 * (L + 1))) == 0) { tc = acc; resolved = true; }  // a head, or the start of the array
+              else lv = L + 1;
+            }
+          }
+          if (pub_level >= zl && resolved) break;
+          if (lv >= kLevels) break;  // cannot happen (level kLevels-1 always reaches the start of the array)
+          if (wall_clock64() - t0 > (unsigned long long)a.patience) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      if (lane == 0 && need_carry) {
+        s_tc[0] = resolved ? tc : id;  // unresolved: outputs stay relative, the follow-up kernel folds the prefix in
+        s_wf[kWaves + 1] = resolved ? 0 : 1;
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- carry into this wave, final values, stores ----------------------------
   float R = s_tc[0];
-  const int unresolved = s_wf[kWaves];
-  bool tile_head = false;
+  const int unresolved = s_wf[kWaves + 1];
 #pragma unroll
-  for (int j = 0; j < kWaves; ++j) {
+  for (int j = 0; j < kWaves; ++j)
     if (j < w) R = s_wf[j] ? s_wv[j] : M::op(R, s_wv[j]);
-    tile_head = tile_head || (s_wf[j] != 0);
+  // ---- level-0 descriptor in its final form (and, for a tile with a head, all its levels), before the stores:
+  //      the tiles behind may be waiting for it ----
+  if (w == kWaves - 1) {
+    if (lt == 0 && lane == 0) {  // per-launch bookkeeping
+      a.hdr[kHdrUnresolved] = 0;
+      a.hdr[kHdrDescResolved] = 0;
+      a.hdr[kHdrTiles + (a.hdr[kHdrEpoch] & 1u)] = (unsigned)a.lvl_off[kLevels];  // what the next launch's follow-up kernel clears
+    }
+    if (a.ntiles > 1) {
+      int first_head;
+      float agg;
+      tile_summary(first_head, agg);
+      const unsigned fl = (has_head ? 0u : kDOpen) | (unresolved ? kDUnresolved : 0u) | ((need_carry && !unresolved) ? kDTree : 0u);
+      if (lane == 0)
+        __hip_atomic_store(entry(0, lt), pack_desc(agg, fl, first_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (has_head && !need_carry && lane >= 1 && lane <= zl)
+        __hip_atomic_store(entry(lane, lt >> (6 * lane)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
@@ -494,26 +659,15 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     R = hmask[r] ? rowtot[r] : M::op(R, rowtot[r]);
   }
 
-  // ---- tile descriptor (only the fallback kernel reads it) -------------------
-  if (lt == 0 && w == kWaves - 1 && lane == 0) a.hdr[2] = 0;  // introspection counter, re-armed per launch
-  if (a.ntiles > 1 && w == kWaves - 1 && lane == 0) {
-    int first_head = kTile;  // elements [0, first_head) of the tile (scan order) take the carry-in
-#pragma unroll
-    for (int j = kWaves - 1; j >= 0; --j)
-      if (s_wf[j]) first_head = j * WT + s_fh[j];
-    uint2 d;
-    d.x = __builtin_bit_cast(unsigned, R);                 // inclusive aggregate of the tile's tail group
-    // bit 0 = open (aggregate depends on the still unknown carry-in), bit 1 = unresolved,
-    // bits 2.. = first head offset
-    d.y = ((unresolved && !tile_head) ? 1u : 0u) | (unresolved ? 2u : 0u) | ((unsigned)first_head << 2);
-    a.desc[lt] = d;
-  }
 }
 
+// Forward modes: six blocks per CU (<= 80 VGPRs), which the rare descriptor walk must not cost; the reverse modes are
+// left to the register allocator (the backward holds three arrays per element and runs at three blocks per CU).
 template <int MODE, bool ALIGNED, bool CARRY>
-__global__ __launch_bounds__(kThreads) void gcp_scan_main(const ScanArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(Mode<MODE>::kRev ? 1 : 6, Mode<MODE>::kRev ? 8 : 6)))
+void gcp_scan_main(const ScanArgs a) {
   __shared__ float s_wv[kWaves];
-  __shared__ int s_wf[kWaves + 1];
+  __shared__ int s_wf[kWaves + 2];
   __shared__ float s_tc[1];
   __shared__ int s_fh[kWaves];
   const i64 lt = logical_tile((i64)blockIdx.x, a.ntiles, a.xcd_remap);
@@ -541,8 +695,36 @@ __device__ __forceinline__ float fix_one(float out, float cin, float x) {
   return Monoid<MD::kMul>::op(cin, out);
 }
 
+// Every block, whatever it finds, also (i) clears its share of the OTHER descriptor set over the range its last user
+// wrote — the set the next launch on this workspace will publish into — and (ii) counts itself done; the last block
+// to finish advances the launch counter, which flips the sets.  Nobody reads the other set or the counter's parity
+// after that point in this launch, so neither needs a barrier.
+template <int MODE>
+__device__ __forceinline__ void fallback_body(const ScanArgs& a, const uint2* desc);
+
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
+  const unsigned epoch = a.hdr[kHdrEpoch];
+  const unsigned set = epoch & 1u;
+  fallback_body<MODE>(a, reinterpret_cast<const uint2*>(a.desc_sets + set));
+  unsigned long long* const other = a.desc_sets + (set ^ 1u);
+  const i64 n_other = (i64)a.hdr[kHdrTiles + (set ^ 1u)];
+  const i64 per = (n_other + gridDim.x - 1) / gridDim.x;
+  const i64 z0 = (i64)blockIdx.x * per;
+  const i64 z1 = (z0 + per < n_other) ? (z0 + per) : n_other;
+  for (i64 t = z0 + threadIdx.x; t < z1; t += kThreads) other[2 * t] = 0ull;
+  __syncthreads();  // every thread's clears are issued before the block reports itself done
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(a.hdr + kHdrDone, 1u) == gridDim.x - 1) {
+      a.hdr[kHdrDone] = 0;
+      a.hdr[kHdrEpoch] = epoch + 1u;
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void fallback_body(const ScanArgs& a, const uint2* desc) {
   typedef Mode<MODE> MD;
   constexpr bool REV = MD::kRev;
   typedef Monoid<MD::kMul> M;
@@ -561,15 +743,22 @@ __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
   const i64 r1 = (r0 + per < a.ntiles) ? (r0 + per) : a.ntiles;
   if (r0 >= r1) return;
 
-  if (tid == 0) s_any = 0;
+  __shared__ int s_tree;
+  if (tid == 0) { s_any = 0; s_tree = 0; }
   __syncthreads();
-  int mine = 0;
-  for (i64 t = r0 + tid; t < r1; t += kThreads) mine += (int)((a.desc[t].y >> 1) & 1u);
+  int mine = 0, tree = 0;
+  for (i64 t = r0 + tid; t < r1; t += kThreads) {
+    const unsigned fl = desc[2 * t].y;
+    mine += (int)((fl >> 1) & 1u);
+    tree += (int)((fl >> 16) & 1u);
+  }
   if (mine) atomicAdd(&s_any, mine);
+  if (tree) atomicAdd(&s_tree, tree);
   __syncthreads();
   const int n_unres = s_any;
+  if (tid == 0 && s_tree) atomicAdd(a.hdr + kHdrDescResolved, (unsigned)s_tree);
   if (n_unres == 0) return;
-  if (tid == 0) atomicAdd(a.hdr + 2, (unsigned)n_unres);
+  if (tid == 0) atomicAdd(a.hdr + kHdrUnresolved, (unsigned)n_unres);
 
   // 1. prefix entering tile r0 = inclusive aggregate of tile r0-1: walk back 256 descriptors per
   //    step (wave w takes distances 64w+1 .. 64w+64) until a closed tile; every thread ends with C.
@@ -577,7 +766,7 @@ __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
   for (i64 t = r0; t > 0; t -= kThreads) {
     const i64 idx = t - 1 - tid;  // tid 0 = nearest predecessor
     uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 0u);  // before the array: closed, identity
-    if (idx >= 0) d = a.desc[idx];
+    if (idx >= 0) d = desc[2 * idx];
     const bool closed = (d.y & 1u) == 0u;
     const unsigned long long cm = __ballot(closed);
     const int lc = cm ? __builtin_ctzll(cm) : 64;
@@ -600,7 +789,7 @@ __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
     if (w == 0) {
       const i64 t = c0 + lane;
       uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 1u);  // past the range: open, identity, resolved
-      if (t < r1) d = a.desc[t];
+      if (t < r1) d = desc[2 * t];
       const bool closed = (d.y & 1u) == 0u;
       const bool unres = ((d.y >> 1) & 1u) != 0u;
       const unsigned long long cm = __ballot(closed);
@@ -615,7 +804,7 @@ __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
         const int slot = __builtin_popcountll(um & ((1ull << lane) - 1ull));
         s_tile[slot] = (int)(t - c0);
         s_carry[slot] = cin;
-        s_first[slot] = (int)(d.y >> 2);
+        s_first[slot] = (int)((d.y >> 2) & 0x1fffu);
       }
       if (lane == 0) s_cnt = __builtin_popcountll(um);
       const float tot = readlane_f(inc, 63);
@@ -697,13 +886,18 @@ __global__ void gcp_check_groups_kernel(const int* inv, const int* inv_len, i64 
 // ----------------------------------------------------------------------------
 // Host side
 // ----------------------------------------------------------------------------
-inline i64 ws_tiles(i64 n) { return (n + 1023) / 1024; }  // upper bound for any tile size
+// entries of the descriptor tree for n elements: level L has one entry per 64^L tiles
+inline void ws_levels(i64 n, i64* off /*[kLevels + 1]*/) {
+  const i64 t = (n + kTile - 1) / kTile;
+  off[0] = 0;
+  for (int L = 0; L < kLevels; ++L) off[L + 1] = off[L] + (t > 0 ? ((t - 1) >> (6 * L)) + 1 : 1);
+}
 
 size_t ws_bytes_for(i64 n) {
-  const i64 t = ws_tiles(n > 0 ? n : 0);
-  size_t b = kWsHeaderBytes;
-  b += ((size_t)t * 8 + 255) / 256 * 256;   // tile descriptors
-  return b;
+  i64 off[kLevels + 1];
+  ws_levels(n > 0 ? n : 0, off);
+  // header + two interleaved sets of descriptor entries
+  return ((size_t)kWsHeaderBytes + (size_t)off[kLevels] * 2u * 8u + 255u) / 256u * 256u;
 }
 
 struct InternalWs {
@@ -729,11 +923,13 @@ int get_internal_ws(size_t need, hipStream_t stream, void** out) {
     cap = (cap + 255) / 256 * 256;
     GCP_HIP(hipMalloc(&w.ptr, cap));
     w.bytes = cap;
-    GCP_HIP(hipMemsetAsync(w.ptr, 0, kWsHeaderBytes, stream));
+    GCP_HIP(hipMemsetAsync(w.ptr, 0, cap, stream));  // launch counter 0, both descriptor sets clear
   }
   *out = w.ptr;
   return GCP_OK;
 }
+
+std::atomic<long long> g_patience_us{-2};  // -2: not set yet (environment GCP_DESC_WAIT_US, else the default)
 
 int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
@@ -768,16 +964,18 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   } else {
     if (ws_bytes < need || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
   }
-  const i64 t = ws_tiles(n);
   char* p = (char*)ws;
   ScanArgs a;
   a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry;
   a.n = n; a.ntiles = ntiles;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
-  a.desc = (uint2*)p;
-  (void)t;
+  a.desc_sets = (unsigned long long*)p;
+  ws_levels(n, a.lvl_off);
   static const int xcd_remap = env_int("GCP_XCD_REMAP", GCP_XCD_REMAP_DEFAULT);
   a.xcd_remap = xcd_remap;
+  long long us = g_patience_us.load(std::memory_order_relaxed);
+  if (us == -2) { us = env_int("GCP_DESC_WAIT_US", GCP_DESC_WAIT_US); g_patience_us.store(us, std::memory_order_relaxed); }
+  a.patience = us < 0 ? -1 : us * 100;  // wall_clock64() counts at 100 MHz
 
   uintptr_t al = (uintptr_t)in0 | (uintptr_t)key | (uintptr_t)out;
   if (Mode<MODE>::kBwd) al |= (uintptr_t)in1 | (uintptr_t)in2;
@@ -834,7 +1032,7 @@ size_t gcp_workspace_bytes(int64_t n) { return ws_bytes_for((i64)n); }
 
 int gcp_workspace_init(void* ws, size_t ws_bytes, void* stream) {
   if (!ws || ws_bytes < (size_t)kWsHeaderBytes || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
-  GCP_HIP(hipMemsetAsync(ws, 0, kWsHeaderBytes, (hipStream_t)stream));
+  GCP_HIP(hipMemsetAsync(ws, 0, ws_bytes, (hipStream_t)stream));  // launch counter 0, both descriptor sets clear
   return GCP_OK;
 }
 
@@ -907,6 +1105,11 @@ int gcp_check_groups(const int32_t* inv, const int32_t* inv_len, int64_t n, int6
 
 int gcp_tile_elems(void) { return kTile; }
 
+int gcp_set_lookback_wait_us(int64_t us) {
+  g_patience_us.store(us < 0 ? -1 : (long long)us, std::memory_order_relaxed);
+  return GCP_OK;
+}
+
 int gcp_last_fallback_tiles(void* ws, void* stream_, int64_t* n_tiles) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!n_tiles) return GCP_ERR_INVALID_ARGUMENT;
@@ -919,7 +1122,25 @@ int gcp_last_fallback_tiles(void* ws, void* stream_, int64_t* n_tiles) {
     ws = g_ws[dev].ptr;
   }
   unsigned h = 0;
-  GCP_HIP(hipMemcpyAsync(&h, (const char*)ws + 8, sizeof(h), hipMemcpyDeviceToHost, stream));
+  GCP_HIP(hipMemcpyAsync(&h, (const char*)ws + 4 * kHdrUnresolved, sizeof(h), hipMemcpyDeviceToHost, stream));
+  GCP_HIP(hipStreamSynchronize(stream));
+  *n_tiles = (int64_t)h;
+  return GCP_OK;
+}
+
+int gcp_last_lookback_tiles(void* ws, void* stream_, int64_t* n_tiles) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!n_tiles) return GCP_ERR_INVALID_ARGUMENT;
+  *n_tiles = 0;
+  if (!ws) {
+    int dev = 0;
+    GCP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (dev < 0 || dev >= 64 || !g_ws[dev].ptr) return GCP_OK;
+    ws = g_ws[dev].ptr;
+  }
+  unsigned h = 0;
+  GCP_HIP(hipMemcpyAsync(&h, (const char*)ws + 4 * kHdrDescResolved, sizeof(h), hipMemcpyDeviceToHost, stream));
   GCP_HIP(hipStreamSynchronize(stream));
   *n_tiles = (int64_t)h;
   return GCP_OK;

@@ -31,6 +31,8 @@ __all__ = [
     "grouped_cumsum_reverse_carry",
     "check_groups",
     "last_fallback_tiles",
+    "last_lookback_tiles",
+    "set_lookback_wait_us",
     "tile_elems",
 ]
 
@@ -75,7 +77,7 @@ def _workspace(device, stream_handle, n):
     if hit is not None and hit[1] >= n:
         return hit[0]
     need = _lib.load().gcp_workspace_bytes(n + n // 2)
-    # tile descriptors + an introspection counter; stateless, zeroed only so the counter reads 0 before use
+    # launch counter + two alternating sets of tile descriptors: must start zeroed (include/grouped_cumprod_hip.h)
     ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
     _workspaces[key] = (ws, n + n // 2)
     return ws
@@ -202,8 +204,7 @@ def check_groups(inv, inv_len):
     return bad.value
 
 
-def last_fallback_tiles(device=None):
-    """Tiles the most recent scan on the current stream fixed up through the descriptor fallback (synchronises)."""
+def _last_stat(fn_name, device):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     lib = _lib.load()
     out = ctypes.c_int64(0)
@@ -212,9 +213,26 @@ def last_fallback_tiles(device=None):
         hit = _workspaces.get((device.index, stream))
         if hit is None:
             return 0
-        status = lib.gcp_last_fallback_tiles(hit[0].data_ptr(), stream, ctypes.byref(out))
-    _lib.check(status, "gcp_last_fallback_tiles")
+        status = getattr(lib, fn_name)(hit[0].data_ptr(), stream, ctypes.byref(out))
+    _lib.check(status, fn_name)
     return out.value
+
+
+def last_fallback_tiles(device=None):
+    """Tiles of the most recent scan on the current stream that gave up waiting for another tile's descriptor and
+    were finished by the follow-up launch (synchronises).  0 in practice."""
+    return _last_stat("gcp_last_fallback_tiles", device)
+
+
+def last_lookback_tiles(device=None):
+    """Tiles of the most recent scan on the current stream whose group started more than one tile back and that
+    resolved their carry through the in-kernel descriptor look-back (synchronises)."""
+    return _last_stat("gcp_last_lookback_tiles", device)
+
+
+def set_lookback_wait_us(us):
+    """Longest wait for another tile's descriptor (default 200 us); negative = two-pass behaviour (tests, A/B timing)."""
+    _lib.check(_lib.load().gcp_set_lookback_wait_us(int(us)), "gcp_set_lookback_wait_us")
 
 
 def tile_elems():

@@ -157,7 +157,7 @@ def test_full_size_properties_cfg3(device):
     table = torch.pow(torch.tensor(0.5, dtype=torch.float64), torch.arange(0, 4098, dtype=torch.float64)).float()
     assert table[149] > 0 and table[150] == 0
     assert torch.equal(y, table.to(device)[pos])
-    assert gc.last_fallback_tiles(device) == 0  # runs are clipped at 4096 = the look-back window
+    assert gc.last_fallback_tiles(device) == 0 and gc.last_lookback_tiles(device) == 0  # runs are clipped at 4096 = the raw look-back window
     del ones, half, pos, rem
     cut = int(p.inv_len[int(torch.searchsorted(p.inv_len, 16_000_000))].item())
     gc.grouped_cumprod_forward(p.x, p.key, y)

@@ -120,18 +120,30 @@ def test_unaligned_views(device):
         assert_parity(y, co.cumprod_forward(xc, kc), co.cumprod_forward_f64(xc, kc), f"unaligned off={off}")
 
 
-def test_long_groups_use_fallback_and_short_do_not(device):
+def test_long_groups_take_the_descriptor_walk_and_short_do_not(device):
+    """Groups up to one tile behind a tile start are resolved from the raw inputs; longer ones walk the tile
+    descriptors inside the same launch; with the walk switched off (two-pass behaviour) the follow-up kernel does it.
+    Same results every way."""
     gc, co = _mods()
     n = 300000
     key = make_keys(n, "poisson8", 3)
     x = make_values(n, 3)
     y = torch.empty(n, device=device)
     gc.grouped_cumprod_forward(x.to(device), key.to(device), y)
-    assert gc.last_fallback_tiles(device) == 0
+    assert gc.last_fallback_tiles(device) == 0 and gc.last_lookback_tiles(device) == 0
     key = make_keys(n, "runs9000", 3)
     gc.grouped_cumprod_forward(x.to(device), key.to(device), y)
-    assert gc.last_fallback_tiles(device) > 0
-    assert_parity(y, co.cumprod_forward(x, key), co.cumprod_forward_f64(x, key), "fallback")
+    walked, left = gc.last_lookback_tiles(device), gc.last_fallback_tiles(device)
+    assert walked + left > 0 and walked > 0
+    assert_parity(y, co.cumprod_forward(x, key), co.cumprod_forward_f64(x, key), "descriptor walk")
+    try:
+        gc.set_lookback_wait_us(-1)
+        y2 = torch.empty_like(y)
+        gc.grouped_cumprod_forward(x.to(device), key.to(device), y2)
+        assert gc.last_lookback_tiles(device) == 0 and gc.last_fallback_tiles(device) == walked + left
+    finally:
+        gc.set_lookback_wait_us(200)
+    assert_parity(y2, co.cumprod_forward(x, key), co.cumprod_forward_f64(x, key), "follow-up kernel")
 
 
 def test_deterministic(device):
@@ -196,9 +208,21 @@ def test_outputs_that_alias_inputs_are_rejected(device):
     torch.cuda.synchronize()
 
 
+@pytest.fixture(params=[200, 0, -1], ids=["walk", "walk-no-wait", "two-pass"])
+def lookback_mode(request):
+    """The three ways a group longer than the raw window gets its carry: descriptor walk with bounded waiting (the
+    default), the walk without waiting (whatever is not published at the first look goes to the follow-up kernel — a
+    mix of both mechanisms in one launch), and the follow-up kernel alone."""
+    import grouped_cumprod as gc
+
+    gc.set_lookback_wait_us(request.param)
+    yield request.param
+    gc.set_lookback_wait_us(200)
+
+
 @pytest.mark.parametrize("dist", ["one_run", "runs9000", "mixed", "geo80"])
-def test_fallback_many_tiles(device, dist):
-    """> 256 tiles so every block of the fallback kernel owns a multi-tile range, with groups that
+def test_long_groups_many_tiles(device, dist, lookback_mode):
+    """> 256 tiles so every block of the follow-up kernel owns a multi-tile range, with groups that
     span many tiles (and, for one_run, the whole array)."""
     gc, co = _mods()
     n = 3_000_017
@@ -209,7 +233,12 @@ def test_fallback_many_tiles(device, dist):
     y = torch.empty(n, device=device)
     gc.grouped_cumprod_forward(x.to(device), kd, y)
     if dist != "geo80":
-        assert gc.last_fallback_tiles(device) > 0
+        walked, left = gc.last_lookback_tiles(device), gc.last_fallback_tiles(device)
+        assert walked + left > 0
+        if lookback_mode < 0:
+            assert walked == 0
+        if lookback_mode == 200:
+            assert walked > 0
     want = co.cumprod_forward(x, key)
     assert_parity(y, want, co.cumprod_forward_f64(x, key), f"cumprod {dist}")
 

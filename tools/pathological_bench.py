@@ -37,12 +37,20 @@ def main():
         cases[f"groups of {lo}-{hi}"] = torch.repeat_interleave(ids, lens)[:n].contiguous()
     lens = torch.full((n // 80 + 2,), 80, device=dev)
     cases["groups of 80 (reference point)"] = torch.repeat_interleave(torch.arange(lens.numel(), device=dev, dtype=torch.int32), lens)[:n].contiguous()
-    for name, key in cases.items():
-        inv_len = torch.zeros(1, dtype=torch.int32, device=dev)
-        tf = timeit(lambda: gc.grouped_cumprod_forward(x, key, y))
-        fb = gc.last_fallback_tiles(dev)
-        tb = timeit(lambda: gc.grouped_cumprod_backward(x, y, go, key, gi, inv_len))
-        print(f"{name:32s} fwd {tf*1e3:8.1f} us ({12*n/tf/1e6:6.0f} GB/s)  bwd {tb*1e3:8.1f} us ({20*n/tb/1e6:6.0f} GB/s)  fallback tiles {fb}", flush=True)
+    only = sys.argv[1:]  # optional substrings selecting cases (a --pmc run wants one case per process)
+    for mode, wait in (("descriptor walk", 200), ("two-pass (walk off)", -1)):
+        gc.set_lookback_wait_us(wait)
+        print(f"--- {mode}")
+        for name, key in cases.items():
+            if only and not any(o in name for o in only):
+                continue
+            inv_len = torch.zeros(1, dtype=torch.int32, device=dev)
+            tf = timeit(lambda: gc.grouped_cumprod_forward(x, key, y))
+            fb, lb = gc.last_fallback_tiles(dev), gc.last_lookback_tiles(dev)
+            tb = timeit(lambda: gc.grouped_cumprod_backward(x, y, go, key, gi, inv_len))
+            print(f"{name:32s} fwd {tf*1e3:8.1f} us ({12*n/tf/1e6:6.0f} GB/s = {12*n/tf/1e6/80:4.1f} %)  bwd {tb*1e3:8.1f} us "
+                  f"({20*n/tb/1e6:6.0f} GB/s = {20*n/tb/1e6/80:4.1f} %)  tiles: walked {lb}, left to the follow-up kernel {fb}", flush=True)
+    gc.set_lookback_wait_us(200)
 
 
 if __name__ == "__main__":

@@ -11,6 +11,12 @@ kernels BASELINE.json's metric is quoted on.  Workload at every
 owns one cfg3-sized image band (1920x1080 pixels, mean 80 splats/pixel, heavy-tailed, M ~ 1.66e8
 pairs); pixel groups are independent so there is NO data-path collective (weak scaling).
 
+Beside the headline (outside its timed region) the line carries: `config.unclipped` (the same workload without the
+4096 clip of SURVEY.md §8d: the few pixels deeper than one tile's raw look-back window go through the scans' descriptor
+tree), `sharded_frames` (ONE cfg5 / cfg3 frame cut into N slices by sharding.partition_groups: strong scaling, with and
+without the frame gather + gradient scatter — BASELINE.json config 5), `function_level` (rows f1/f2, with the blend
+backward's issue roofline and lane use), `caller_level` (row f4).
+
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the backward scan):
 algorithmic bytes (20 B x pairs per launch) / its mean duration measured with HIP events on the
 launch stream inside the timed region.  `cpu_baseline` times the oracle's sequential C port of the
@@ -97,6 +103,44 @@ def cpu_baseline(p, sample_pairs):
     }
 
 
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4  # 1024 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes wide) at 2.4 GHz
+
+
+def lane_use(bins, start, end):
+    """How full the waves of the blend kernels are: a (wave, list entry) visit costs the same VALU issue slots whether 1
+    or 64 of the wave's pixels (4 rows x 16 columns) lie inside the entry's box.  Computed from the tile lists: per
+    (tile, Gaussian) entry the box's columns and rows inside the tile -> pixels inside, and the waves (4-row groups) it
+    reaches.  Returns (wave-entry visits, lanes inside a box / lanes issued)."""
+    import torch
+
+    K = bins.n_tile_pairs
+    if K == 0:
+        return 0, None
+    dev = start.device
+    tile = torch.searchsorted(bins.tile_start[1:].contiguous(), torch.arange(K, device=dev, dtype=torch.int32), right=True)
+    g = bins.tile_list.long()
+    tx0 = (tile % bins.tiles_x) * 16
+    ty0 = (tile // bins.tiles_x) * 16
+    x0 = torch.maximum(start[g, 0].clamp(min=0).long(), tx0)
+    x1 = torch.minimum(end[g, 0].clamp(max=bins.width).long(), tx0 + 15)
+    y0 = torch.maximum(start[g, 1].clamp(min=0).long(), ty0)
+    y1 = torch.minimum(end[g, 1].clamp(max=bins.height).long(), ty0 + 15)
+    cols = (x1 - x0 + 1).clamp(min=0)
+    rows = (y1 - y0 + 1).clamp(min=0)
+    waves = ((y1 - ty0) // 4 - (y0 - ty0) // 4 + 1).clamp(min=0) * (rows > 0)
+    visits = int(waves.sum())
+    return visits, float((cols * rows).sum()) / (64.0 * max(visits, 1))
+
+
+def pmc_function(kernel, workload, counter):
+    """A counter of the committed rocprofv3 --pmc pass over tools/raster_bench.py (profiles/pmc_function.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_function.json")) as f:
+            return json.load(f)[workload][kernel][counter]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def function_level(dev, workload):
     """Rows f1/f2 (outside the timed region, informational): the whole rasterise-and-blend Function of the
     reference (gs_model.py:666-692, :786-820) on a scene of the same shape — tile binning, fused blend
@@ -127,6 +171,20 @@ def function_level(dev, workload):
     (img, ckpt), t_fwd = timed(lambda: raster.blend_forward(bins, *params, with_checkpoints=True))
     gimg = torch.randn_like(img)
     _, t_bwd = timed(lambda: raster.blend_backward(bins, *params, ckpt, gimg))
+    visits, lane_frac = lane_use(bins, sc["start"], sc["end"])
+    insts = pmc_function("k_blend_bwd", workload, "SQ_INSTS_VALU")
+    roof = {
+        "kernel": "k_blend_bwd (fused blend backward; HBM traffic is K x 64 B + checkpoints + image: far from the HBM roof)",
+        "bound": "valu-issue",
+        "insts": insts,  # VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_function.json)
+        "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
+        "achieved_wave_insts_per_s": None if insts is None else insts / (t_bwd * 1e-3),
+        "frac": None if insts is None else insts / (t_bwd * 1e-3) / VALU_PEAK_WAVE_INSTS,
+        "wave_entry_visits": visits,
+        "valu_per_visit": None if insts is None or not visits else insts / visits,
+        "active_lane_frac": lane_frac,  # pixels inside the visited entry's box / 64 lanes issued
+        "avg_launch_us": t_bwd * 1e3,
+    }
     return {
         "what": "custom_autograd_grouped_cumprod: tile binning + fused blend forward + backward (no pair list materialised)",
         "gaussians": int(sc["start"].size(0)),
@@ -136,6 +194,7 @@ def function_level(dev, workload):
         "forward_ms": t_fwd,
         "backward_ms": t_bwd,
         "pairs_per_s": pairs / ((t_bin + t_fwd + t_bwd) * 1e-3),
+        "roofline": roof,
     }
 
 
@@ -184,6 +243,80 @@ def caller_level(dev, workload):
         "reference_formulation_ms": "179 (projection and loss as PyTorch ops around the same Function; tests/bench_reference_caller_gpu.py)",
         "pairs_per_s": pairs / (fused_ms * 1e-3),
     }
+
+
+def sharded_frame(name, world, rank, device, scan_fwd_bwd, sync, steps=10, warmup=3, collectives=True, max_run=None):
+    """BASELINE.json config 5's shape (and the strong-scaling form of config 3): ONE frame of config `name`, its pair
+    list cut into `world` slices at pixel-group boundaries (sharding.partition_groups), every rank scanning its slice
+    with no data-path collective; then the only exchange the design has — one gather of per-group rows to rank 0 (frame
+    assembly) and one scatter back (dL/dI distribution) — timed on its own.  Returns a dict on every rank (identical
+    numbers: times are max over ranks).  `scan_fwd_bwd(p)` runs grouped_cumprod forward + backward on a PairList (the HIP
+    library in bench.py; tests inject the oracle to rehearse this exact control flow on CPU with gloo);
+    `sync()` = barrier + device synchronise."""
+    import torch
+    import torch.distributed as dist
+
+    from simplegaussiansplat_tk71_amd import sharding, synthetic
+
+    kw = {} if max_run is None else {"max_run": max_run}
+    p, shards, total_pairs = synthetic.make_config_slice(name, world, rank, seed=0, device=device, **kw)
+    for _ in range(warmup):
+        scan_fwd_bwd(p)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        scan_fwd_bwd(p)
+    sync()
+    t_scan = (time.perf_counter() - t0) / steps
+    out = {
+        "workload": f"{name}: ONE {synthetic.CONFIGS[name]['width']}x{synthetic.CONFIGS[name]['height']} frame, "
+                    f"{total_pairs} pairs, cut into {world} slice(s) at pixel-group boundaries nearest k*M/N",
+        "total_pairs": total_pairs,
+        "pairs_per_rank": [s.n_pairs for s in shards],
+        "groups_per_rank": [s.n_groups for s in shards],
+        "steps": steps,
+    }
+    gather_s = scatter_s = None
+    err = None
+    if world > 1:
+        t = torch.tensor([t_scan], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_scan = float(t.item())
+        if collectives:
+            try:
+                rows = torch.rand(p.n_groups, 3, device=device)  # per-pixel colour of this slice's groups
+                tg = ts = 0.0
+                reps = 3
+                for it in range(reps + 1):
+                    sync()
+                    t1 = time.perf_counter()
+                    full = sharding.gather_groups(rows, shards, dst=0)
+                    sync()
+                    t2 = time.perf_counter()
+                    back = sharding.scatter_groups(full, shards, like=rows, src=0)
+                    sync()
+                    t3 = time.perf_counter()
+                    if it:  # first round = RCCL channel set-up
+                        tg += t2 - t1
+                        ts += t3 - t2
+                bad = 0.0 if torch.equal(back, rows) else 1.0  # round trip must be the identity
+                tt = torch.tensor([tg / reps, ts / reps, bad], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                if float(tt[2]) != 0.0:
+                    err = "gather/scatter round trip is not the identity"
+                else:
+                    gather_s, scatter_s = float(tt[0]), float(tt[1])
+            except Exception as e:  # recorded in the JSON line, never swallowed: a RCCL failure must show in SCALE_r*.json
+                err = repr(e)
+    out.update({
+        "scan_ms_per_step": t_scan * 1e3,
+        "pairs_per_s_scan_only": total_pairs / t_scan,
+        "frame_gather_ms": None if gather_s is None else gather_s * 1e3,
+        "grad_scatter_ms": None if scatter_s is None else scatter_s * 1e3,
+        "pairs_per_s_with_gather_scatter": None if gather_s is None else total_pairs / (t_scan + gather_s + scatter_s),
+        "collective_error": err,
+    })
+    return out
 
 
 def pmc_traffic(kernel, workload):
@@ -243,6 +376,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
+            sys.exit(f"process group has {dist.get_world_size()} ranks (rank {dist.get_rank()}), expected --gpus {args.gpus} (RANK {rank})")
+        if rank == 0:
+            print(f"[bench] process group up: backend {backend}, world size {dist.get_world_size()}", file=sys.stderr, flush=True)
 
     # this rank's band of the frame; bands are independent pair lists (no exchange on the scan path)
     if args.workload == "cfg5band":
@@ -303,33 +440,68 @@ def main():
     else:
         total_pairs = float(m)
 
-    # frame assembly / gradient distribution (outside the timed region; the scan path has no collective)
-    gather_ms = scatter_ms = None
-    if world > 1 and backend == "nccl" and os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1":
-        try:
-            from simplegaussiansplat_tk71_amd import sharding
+    # ---- outside the timed region ------------------------------------------------------------------------------
+    walked = gc.last_lookback_tiles(dev)
 
-            counts = torch.tensor([p.n_groups, m], dtype=torch.int64, device=dev)
-            allc = [torch.empty_like(counts) for _ in range(world)]
-            dist.all_gather(allc, counts)
-            shards = sharding.shards_from_counts([int(c[0]) for c in allc], [int(c[1]) for c in allc])
-            rows = torch.rand(p.n_groups, 3, device=dev)
-            for it in range(3):
-                sync()
-                t1 = time.perf_counter()
-                full = sharding.gather_groups(rows, shards, dst=0)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                back = sharding.scatter_groups(full, shards, like=rows, src=0)
-                torch.cuda.synchronize()
-                t3 = time.perf_counter()
-            bad = 0.0 if torch.equal(back, rows) else 1.0  # round trip must be the identity
-            tt = torch.tensor([t2 - t1, t3 - t2, bad], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            if float(tt[2]) == 0.0:
-                gather_ms, scatter_ms = float(tt[0]) * 1e3, float(tt[1]) * 1e3
-        except Exception as e:  # never let the optional collective timing break the headline number
-            print(f"[rank {rank}] gather/scatter timing skipped: {e!r}", file=sys.stderr)
+    def scan_fwd_bwd(q):
+        yy = scan_fwd_bwd.buf.setdefault(("y", q.n_pairs), torch.empty_like(q.x))
+        gg = scan_fwd_bwd.buf.setdefault(("g", q.n_pairs), torch.empty_like(q.x))
+        gc.grouped_cumprod_forward(q.x, q.key, yy)
+        gc.grouped_cumprod_backward(q.x, yy, q.grad_out, q.inv, gg, q.inv_len)
+
+    scan_fwd_bwd.buf = {}
+
+    # BASELINE.json config 5 (and config 3 in strong-scaling form): ONE frame cut into `world` slices
+    sharded = {}
+    if os.environ.get("GCP_BENCH_NO_SHARDED", "0") != "1":
+        for name in ("cfg5", "cfg3"):
+            if backend != "nccl" and world > 1:
+                break  # the gloo rehearsal of this control flow lives in tests/test_sharding.py (CPU tensors)
+            free, _ = torch.cuda.mem_get_info(dev)
+            c = synthetic.CONFIGS[name]
+            est = c["height"] * c["width"] * c["mean_depth"] / world * 4 * 12  # slice arrays + generation temporaries
+            if free < est:
+                sharded[name] = {"skipped": f"needs ~{est / 2**30:.0f} GiB of HBM per rank, {free / 2**30:.0f} GiB free"}
+                continue
+            sharded[name] = sharded_frame(name, world, rank, dev, scan_fwd_bwd, sync, steps=10, warmup=3,
+                                          collectives=os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1")
+            scan_fwd_bwd.buf.clear()
+            torch.cuda.empty_cache()
+
+    # the same workload without the 4096 clip: a handful of pixels deeper than one tile's raw look-back window
+    unclipped = None
+    if world == 1 and args.workload in synthetic.CONFIGS:
+        q = synthetic.make_config(args.workload, seed=rank, device=dev, max_run=None)
+        for _ in range(3):
+            scan_fwd_bwd(q)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        yy, gg = scan_fwd_bwd.buf[("y", q.n_pairs)], scan_fwd_bwd.buf[("g", q.n_pairs)]
+        reps = 10
+        tf = tb = 0.0
+        for _ in range(reps):
+            e0.record()
+            gc.grouped_cumprod_forward(q.x, q.key, yy)
+            e1.record()
+            gc.grouped_cumprod_backward(q.x, yy, q.grad_out, q.inv, gg, q.inv_len)
+            e2.record()
+            torch.cuda.synchronize()
+            tf += e0.elapsed_time(e1)
+            tb += e1.elapsed_time(e2)
+        unclipped = {
+            "workload": f"{args.workload} without the clip at 4096 splats per pixel",
+            "pairs": q.n_pairs,
+            "longest_pixel_list": int(q.run_len.max()),
+            "pixels_deeper_than_4096": int((q.run_len > 4096).sum()),
+            "pairs_per_s": q.n_pairs / ((tf + tb) / reps * 1e-3),
+            "forward_us": tf / reps * 1e3,
+            "backward_us": tb / reps * 1e3,
+            "fwd_plus_bwd_frac_of_hbm_peak": (BYTES_FWD + BYTES_BWD) * q.n_pairs / ((tf + tb) / reps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "tiles_resolved_through_the_descriptor_tree": gc.last_lookback_tiles(dev),
+            "tiles_left_to_the_follow_up_kernel": gc.last_fallback_tiles(dev),
+        }
+        del q, yy, gg
+        scan_fwd_bwd.buf.clear()
+        torch.cuda.empty_cache()
 
     if rank == 0:
         ach = BYTES_BWD * m / t_bwd / 1e9
@@ -353,10 +525,12 @@ def main():
                 "sharding": "one image band per GPU, no data-path collective" if world > 1 else "single GPU",
                 "bytes_per_pair": BYTES_FWD + BYTES_BWD,
                 "aggregate_algorithmic_GBps": (BYTES_FWD + BYTES_BWD) * total_pairs * args.steps / elapsed / 1e9,
-                "fallback_tiles_last_launch": fallback,
-                "frame_gather_ms": gather_ms,
-                "grad_scatter_ms": scatter_ms,
+                "tiles_left_to_the_follow_up_kernel": fallback,
+                "tiles_resolved_through_the_descriptor_tree": walked,
+                "world_size_checked": world,
+                "unclipped": unclipped,
             },
+            "sharded_frames": sharded,
             "roofline": {
                 "kernel": "gcp_scan_main<CUMPROD_BWD> (grouped_cumprod_backward)",
                 "bound": "hbm",

@@ -48,50 +48,89 @@ class PairList:
         return self.inv_len.numel()
 
 
-def run_lengths(n_pixels, mean_depth, deep, generator, device):
+def run_lengths(n_pixels, mean_depth, deep, generator, device, max_run=MAX_RUN):
     """Splats per pixel.  Poisson(D), or for "deep per-pixel lists" the mix
-    0.9*Poisson(D/2) + 0.1*Geometric(mean 5.5*D) (same mean D), clipped at 4096."""
+    0.9*Poisson(D/2) + 0.1*Geometric(mean 5.5*D) (same mean D), clipped at `max_run` (4096 = SURVEY.md §8d; None = no
+    clip: the "cfg3_unclipped" workload, whose few pixels deeper than 4096 exercise the scans' descriptor tree)."""
+    if max_run is None:
+        max_run = 1 << 30
     if not deep:
         lam = torch.full((n_pixels,), float(mean_depth), device=device)
-        return torch.poisson(lam, generator=generator).long().clamp_(max=MAX_RUN)
+        return torch.poisson(lam, generator=generator).long().clamp_(max=max_run)
     lam = torch.full((n_pixels,), float(mean_depth) / 2.0, device=device)
     body = torch.poisson(lam, generator=generator)
     u = torch.rand(n_pixels, device=device, generator=generator)
     p = 1.0 / (5.5 * float(mean_depth))
     v = torch.rand(n_pixels, device=device, generator=generator).clamp_(min=1e-12)
     tail = torch.floor(torch.log(v) / torch.log1p(torch.tensor(-p, device=device))) + 1.0
-    return torch.where(u < 0.1, tail, body).long().clamp_(min=0, max=MAX_RUN)
+    return torch.where(u < 0.1, tail, body).long().clamp_(min=0, max=max_run)
 
 
-def make_pairs(height, width, mean_depth, deep=False, seed=0, device="cpu", row_start=0, gaussians=None):
-    """Pair list of an image band of `height` rows starting at image row `row_start`."""
-    del gaussians  # enters only through mean_depth (SURVEY.md §8d)
-    device = torch.device(device)
-    g = torch.Generator(device=device)
-    g.manual_seed(int(seed))
-    n_pixels = height * width
-    L = run_lengths(n_pixels, mean_depth, deep, g, device)
+def pixel_keys(height, width, device, row_start=0):
+    """The reference's pixel key y*10000 + x (gs_model.py:538-541) of every pixel of a band, row-major."""
     ys = torch.arange(row_start, row_start + height, device=device, dtype=torch.int32)
     xs = torch.arange(width, device=device, dtype=torch.int32)
-    pixel_key = (ys[:, None] * 10000 + xs[None, :]).reshape(-1)
+    return (ys[:, None] * 10000 + xs[None, :]).reshape(-1)
+
+
+def pairs_from_runs(L, pixel_key, generator, height, width):
+    """Pair list of the pixels `pixel_key` with `L` splats each (zeros allowed): keys, dense group ids, end offsets and
+    seeded values."""
+    device = L.device
     key = torch.repeat_interleave(pixel_key, L)
     m = key.numel()
     nz = L > 0
     inv_len = torch.cumsum(L[nz], 0).to(torch.int32)
     inv = torch.repeat_interleave(torch.arange(int(nz.sum()), device=device, dtype=torch.int32), L[nz])
     # opacity ~ sigmoid(N(1.7, 2.0)) clipped to [0.005, 0.995]: quantiles of the reference's opacity.pt
-    a = torch.sigmoid(torch.randn(m, device=device, generator=g) * 2.0 + 1.7).clamp_(0.005, 0.995)
-    gk = torch.rand(m, device=device, generator=g)
+    a = torch.sigmoid(torch.randn(m, device=device, generator=generator) * 2.0 + 1.7).clamp_(0.005, 0.995)
+    gk = torch.rand(m, device=device, generator=generator)
     x = 1.0 - a * gk
-    grad_out = torch.randn(m, device=device, generator=g)
+    grad_out = torch.randn(m, device=device, generator=generator)
     return PairList(key, x, inv, inv_len, grad_out, L, height, width)
 
 
-def make_config(name, seed=0, device="cpu", rows=None, row_start=0):
+def make_pairs(height, width, mean_depth, deep=False, seed=0, device="cpu", row_start=0, gaussians=None, max_run=MAX_RUN):
+    """Pair list of an image band of `height` rows starting at image row `row_start`."""
+    del gaussians  # enters only through mean_depth (SURVEY.md §8d)
+    device = torch.device(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    L = run_lengths(height * width, mean_depth, deep, g, device, max_run)
+    return pairs_from_runs(L, pixel_keys(height, width, device, row_start), g, height, width)
+
+
+def make_config(name, seed=0, device="cpu", rows=None, row_start=0, max_run=MAX_RUN):
     """One of BASELINE.json's configs; `rows` restricts it to an image band."""
     c = CONFIGS[name]
     h = c["height"] if rows is None else rows
-    return make_pairs(h, c["width"], c["mean_depth"], c["deep"], seed, device, row_start)
+    return make_pairs(h, c["width"], c["mean_depth"], c["deep"], seed, device, row_start, max_run=max_run)
+
+
+def make_config_slice(name, world_size, rank, seed=0, device="cpu", max_run=MAX_RUN):
+    """Rank `rank`'s share of ONE frame of config `name` cut into `world_size` contiguous slices at the pixel-group
+    boundaries nearest k*M/R (sharding.partition_groups: balance by pairs, not by rows — SURVEY.md §8e).  Every rank
+    draws the same per-pixel run lengths (same seed), so all ranks agree on the cut without communicating; only the
+    owned slice's pair arrays are materialised.  Returns (PairList of the slice with ids / offsets rebased to it, the
+    Shard table, total pairs of the frame)."""
+    from . import sharding
+
+    c = CONFIGS[name]
+    device = torch.device(device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    h, w = c["height"], c["width"]
+    L = run_lengths(h * w, c["mean_depth"], c["deep"], g, device, max_run)
+    nz = torch.nonzero(L > 0).flatten()
+    ends = torch.cumsum(L[nz], 0)
+    shards = sharding.partition_groups(ends, world_size)
+    sh = shards[rank]
+    own = nz[sh.group_start : sh.group_end]
+    gl = torch.Generator(device=device)
+    gl.manual_seed(int(seed) * 1000003 + 17 * rank + 1)
+    p = pairs_from_runs(L[own], pixel_keys(h, w, device)[own], gl, h, w)
+    assert p.n_pairs == sh.n_pairs and p.n_groups == sh.n_groups
+    return p, shards, int(ends[-1].item()) if ends.numel() else 0
 
 
 def make_scene(n_gauss, width, height, mean_depth, seed=0, device="cpu"):

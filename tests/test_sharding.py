@@ -194,3 +194,85 @@ def test_more_ranks_than_tile_rows_empty_bands_join_the_collectives():
     for pr in procs:
         pr.join(60)
         assert pr.exitcode == 0
+
+
+def _bench_worker(rank, world, port, q):
+    """The multi-GPU block of bench.py (sharded_frame) with the oracle standing in for the HIP scans and gloo for RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from oracle import c_oracle as co
+
+        seen = {}
+
+        def scan_fwd_bwd(p):
+            y = co.cumprod_forward(p.x, p.key)
+            g = co.cumprod_backward_f64(p.x, y, p.grad_out, p.inv)
+            seen["checksum"] = (float(y.double().sum()), float(g.sum()), p.n_pairs, p.n_groups)
+
+        def sync():
+            dist.barrier()
+
+        out = bench.sharded_frame("cfg1", world, rank, torch.device("cpu"), scan_fwd_bwd, sync, steps=2, warmup=1)
+        q.put((rank, out, seen["checksum"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_bench_sharded_frame_block_two_rank_gloo_rehearsal():
+    """bench.py --gpus N adds a `sharded_frames` block (BASELINE.json config 5: ONE frame cut by partition_groups,
+    pairs/s with and without the frame gather + gradient scatter).  Rehearsal of exactly that function on two gloo ranks:
+    both ranks report the same numbers, the slices tile the frame, the collectives ran (no collective_error) and their
+    round trip is the identity."""
+    from simplegaussiansplat_tk71_amd import synthetic
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted((q.get(timeout=200) for _ in range(world)), key=lambda t: t[0])
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    (r0, o0, c0), (r1, o1, c1) = got
+    assert o0 == o1  # every rank holds the same report (times are max-reduced)
+    assert o0["collective_error"] is None
+    assert o0["frame_gather_ms"] is not None and o0["grad_scatter_ms"] is not None
+    assert o0["pairs_per_s_with_gather_scatter"] < o0["pairs_per_s_scan_only"]
+    whole = synthetic.make_config("cfg1", seed=0)  # same seed: the slices are a cut of this frame's run lengths
+    assert o0["total_pairs"] == whole.n_pairs == sum(o0["pairs_per_rank"])
+    assert sum(o0["groups_per_rank"]) == whole.n_groups
+    assert (c0[2], c1[2]) == tuple(o0["pairs_per_rank"]) and (c0[3], c1[3]) == tuple(o0["groups_per_rank"])
+    assert abs(o0["pairs_per_rank"][0] - o0["pairs_per_rank"][1]) <= 64  # balanced by pairs, cut at a group boundary
+
+
+def test_bench_sharded_frame_reports_a_collective_failure(monkeypatch):
+    """A failing collective must end up in the JSON line (`collective_error`), not on stderr only."""
+    import bench
+
+    class Boom(RuntimeError):
+        pass
+
+    def broken(*a, **k):
+        raise Boom("RCCL says no")
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(sharding, "gather_groups", broken)
+        # world = 1 skips the collectives; pretend to be one rank of two for the branch that times them
+        monkeypatch.setattr(sharding, "partition_groups", lambda ends, w: [sharding.Shard(0, 0, ends.numel(), 0, int(ends[-1])),
+                                                                            sharding.Shard(1, ends.numel(), ends.numel(), int(ends[-1]), int(ends[-1]))])
+        out = bench.sharded_frame("cfg1", 2, 0, torch.device("cpu"), lambda p: None, lambda: None, steps=1, warmup=0)
+    finally:
+        dist.destroy_process_group()
+    assert out["collective_error"] is not None and "RCCL says no" in out["collective_error"]
+    assert out["frame_gather_ms"] is None and out["pairs_per_s_with_gather_scatter"] is None

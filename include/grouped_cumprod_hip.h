@@ -202,6 +202,17 @@ int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n
                        int64_t n_tile_pairs, int32_t* tile_start, int32_t* tile_list, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* The same binning in ONE call without a host read-back (graph-capturable): the caller bounds the entry count by
+ * `capacity` (tile_list has `capacity` slots, ws = gcp_bin_workspace_bytes(n_gauss, capacity)); the real count stays on
+ * the device.  info[0] = entries listed, info[1] = 1 if the capacity was too small — Gaussians whose entries did not
+ * fit are then left out (front-most first kept) and get zero gradients; the caller reads info once per step, after the
+ * fact, instead of synchronising inside the Function (the reference synchronises on `.item()` calls per chunk,
+ * gs_model.py:677,793,801-802).  Buffers derived from the bins (checkpoints, backward workspace) are sized by
+ * `capacity`, and `capacity` is what gcp_blend_backward takes as n_tile_pairs. */
+int gcp_bin_tiles(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
+                  int32_t height, int64_t capacity, int32_t* tile_off, int32_t* tile_start,
+                  int32_t* tile_list, int32_t* info, void* ws, size_t ws_bytes, void* stream);
+
 /* f1 forward: image = sum over pairs of T * l * o * g with T the exclusive grouped cumprod of
  * (1 - o g) per pixel in depth order; pairs whose inclusive product is exactly 0 are dropped.
  * Replaces _forward_batch + index_put_(accumulate=True) (gs_model.py:598-624, :510-514).

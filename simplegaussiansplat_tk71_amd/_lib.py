@@ -51,6 +51,10 @@ SIGNATURES = {
         ctypes.c_int,
         [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p],
     ),
+    "gcp_bin_tiles": (
+        ctypes.c_int,
+        [_c_void_p, _c_void_p, _i64, _i32, _i32, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p],
+    ),
     "gcp_blend_checkpoint_floats": (_sz, [_i64, _i32, _i32]),
     "gcp_blend_forward": (
         ctypes.c_int,

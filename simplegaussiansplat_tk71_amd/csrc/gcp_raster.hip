@@ -174,10 +174,23 @@ __global__ __launch_bounds__(256) void k_tile_count(const int* start, const int*
   if (threadIdx.x == 0 && s_total) atomicAdd(total64, s_total);
 }
 
+// `capacity` / `info` (capture-safe binning, gcp_bin_tiles): a Gaussian whose entries do not fit below `capacity` is
+// left out together with everything behind it; info[0] = entries actually listed, info[1] = 1 if anything was left out.
 __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
-                            const int* off, unsigned* key, unsigned* val) {
+                            const int* off, unsigned* key, unsigned* val, i64 capacity, int* info,
+                            const unsigned long long* total64) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
+  if (info) {
+    if (*total64 > 0x7fffffffull) {  // the int32 prefix sums have wrapped: nothing can be listed
+      if (g == 0) { info[0] = 0; info[1] = 1; }
+      return;
+    }
+    const i64 lo = off[g], hi = off[g + 1];
+    if (g == 0 && (i64)off[n] <= capacity) { info[0] = off[n]; info[1] = 0; }
+    if (lo <= capacity && hi > capacity) { info[0] = (int)lo; info[1] = 1; }  // the one Gaussian that straddles the bound
+    if (hi > capacity) return;
+  }
   Box b;
   if (!load_box(start, end, g, W, H, b)) return;
   int e = off[g];
@@ -202,8 +215,11 @@ __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int 
 // ------------------------------------------------------------------------------------------
 constexpr int kSortChunk = 4096;    // keys per radix-sort block
 
-__global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk) {
+// n_dev (optional): the number of keys lives on the device (capture-safe binning); n is then only the bound the grid was
+// sized for, and blocks past the real count contribute empty histograms / copy nothing
+__global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk, const int* n_dev) {
   __shared__ int h[256];
+  if (n_dev) n = min(n, (i64)*n_dev);
   h[threadIdx.x] = 0;
   __syncthreads();
   const i64 base = (i64)blockIdx.x * kSortChunk;
@@ -217,7 +233,8 @@ __global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, i
 template <bool FIRST>  // FIRST: the payload is the element's own index
 __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
                                                        unsigned* val_out, i64 n, int shift, const int* hist_excl,
-                                                       int nblk) {
+                                                       int nblk, const int* n_dev) {
+  if (n_dev) n = min(n, (i64)*n_dev);
   __shared__ unsigned s_key[kSortChunk];
   __shared__ unsigned s_val[kSortChunk];
   __shared__ int off[4][256];   // (A) per-wave digit counts -> (B) first LDS slot of (wave, digit)
@@ -281,7 +298,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
 }
 
 // tile_start[t] = first sorted entry whose tile id is >= t, for t in [0, n_tiles]
-__global__ void k_tile_bounds(const unsigned* key, i64 K, int n_tiles, int* tile_start) {
+__global__ void k_tile_bounds(const unsigned* key, i64 K, int n_tiles, int* tile_start, const int* n_dev) {
+  if (n_dev) K = min(K, (i64)*n_dev);
   const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i > K) return;
   const int prev = (i == 0) ? -1 : (int)key[i - 1];
@@ -647,14 +665,16 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
 
 // per Gaussian: sum its tile slots in order, expand the moments into the four gradients
 __global__ void k_grad_reduce(const float* __restrict__ partial, const int* __restrict__ tile_off,
-                              const float* __restrict__ vinv, i64 n, float* grad_mean, float* grad_vinv,
+                              const float* __restrict__ vinv, i64 n, i64 capacity, float* grad_mean, float* grad_vinv,
                               float* grad_opacity, float* grad_l) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   float r[kGradVals];
 #pragma unroll
   for (int v = 0; v < kGradVals; ++v) r[v] = 0.0f;
-  for (i64 e = tile_off[g]; e < tile_off[g + 1]; ++e)
+  // (a Gaussian whose entries did not fit below the capacity of a capture-safe binning was never listed: zeros)
+  const i64 e1 = (i64)tile_off[g + 1] <= capacity ? (i64)tile_off[g + 1] : (i64)tile_off[g];
+  for (i64 e = tile_off[g]; e < e1; ++e)
 #pragma unroll
     for (int v = 0; v < kGradVals; ++v) r[v] += partial[e * kGradVals + v];
   const float A = vinv[4 * g], B = vinv[4 * g + 1], C = vinv[4 * g + 2], D = vinv[4 * g + 3];
@@ -832,7 +852,51 @@ size_t gcp_bin_workspace_bytes(int64_t n_gauss, int64_t n_tile_pairs) {
   b += gcp_scan_i32_workspace_bytes(256 * nblk);
   const size_t count_need = 256 + align256((size_t)(n_gauss > 0 ? n_gauss : 1) * sizeof(int)) +
                             gcp_scan_i32_workspace_bytes(n_gauss > 0 ? n_gauss : 1);
-  return b > count_need ? b : count_need;
+  return (b > count_need ? b : count_need) + 512;  // + room for gcp_bin_tiles' 64-bit total behind everything else
+}
+
+// emit + stable sort by tile + tile bounds; `info` non-null = capture-safe mode (K is the capacity, the real count is info[0])
+static int bin_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                    const int32_t* tile_off, int64_t K, int32_t* tile_start, int32_t* tile_list, int* info,
+                    const unsigned long long* total64, void* ws, hipStream_t stream) {
+  const TileGrid tg = tile_grid(width, height);
+  const int n_tiles = tg.tx * tg.ty;
+  const i64 nblk = (K + kSortChunk - 1) / kSortChunk;
+  char* p = (char*)ws;
+  unsigned* keyA = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  unsigned* keyB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  unsigned* valB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
+  int* hist = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* hist_ex = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
+  int* sws = (int*)p;
+  unsigned* valA = (unsigned*)tile_list;  // the caller's output buffer doubles as one value buffer
+  const int* n_dev = info;                // info[0] = entries listed
+
+  hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
+                     (i64)n_gauss, width, height, tg.tx, tile_off, keyA, valA, (i64)K, info, total64);
+  GCP_HIP(hipGetLastError());
+  int bits = 1;
+  while ((1 << bits) < n_tiles) ++bits;
+  int passes = (bits + 7) / 8;
+  if (passes & 1) ++passes;  // even number of passes: the result lands back in (keyA, valA = tile_list)
+  unsigned *ks = keyA, *vs = valA, *kd = keyB, *vd = valB;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks, K, shift, hist, (int)nblk, n_dev);
+    GCP_HIP(hipGetLastError());
+    const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
+    if (st != GCP_OK) return st;
+    hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks,
+                       (const unsigned*)vs, kd, vd, K, shift, (const int*)hist_ex, (int)nblk, n_dev);
+    GCP_HIP(hipGetLastError());
+    unsigned* t;
+    t = ks; ks = kd; kd = t;
+    t = vs; vs = vd; vd = t;
+  }
+  hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256), 0, stream, ks, K, n_tiles,
+                     tile_start, n_dev);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
 }
 
 int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width,
@@ -849,41 +913,40 @@ int gcp_bin_tiles_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n
   }
   if (!start_xy || !end_xy || !tile_off || !tile_list || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_bin_workspace_bytes(n_gauss, K)) return GCP_ERR_WORKSPACE;
-  const i64 nblk = (K + kSortChunk - 1) / kSortChunk;
-  char* p = (char*)ws;
-  unsigned* keyA = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
-  unsigned* keyB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
-  unsigned* valB = (unsigned*)p; p += align256((size_t)K * sizeof(unsigned));
-  int* hist = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
-  int* hist_ex = (int*)p; p += align256((size_t)(256 * nblk + 1) * sizeof(int));
-  int* sws = (int*)p;
-  unsigned* valA = (unsigned*)tile_list;  // the caller's output buffer doubles as one value buffer
+  return bin_fill(start_xy, end_xy, n_gauss, width, height, tile_off, K, tile_start, tile_list, nullptr, nullptr, ws, stream);
+}
 
-  hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
-                     (i64)n_gauss, width, height, tg.tx, tile_off, keyA, valA);
-  GCP_HIP(hipGetLastError());
-  int bits = 1;
-  while ((1 << bits) < n_tiles) ++bits;
-  int passes = (bits + 7) / 8;
-  if (passes & 1) ++passes;  // even number of passes: the result lands back in (keyA, valA = tile_list)
-  unsigned *ks = keyA, *vs = valA, *kd = keyB, *vd = valB;
-  for (int pass = 0; pass < passes; ++pass) {
-    const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks, K, shift, hist, (int)nblk);
-    GCP_HIP(hipGetLastError());
-    const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
-    if (st != GCP_OK) return st;
-    hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks,
-                       (const unsigned*)vs, kd, vd, K, shift, (const int*)hist_ex, (int)nblk);
-    GCP_HIP(hipGetLastError());
-    unsigned* t;
-    t = ks; ks = kd; kd = t;
-    t = vs; vs = vd; vd = t;
+int gcp_bin_tiles(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                  int64_t capacity, int32_t* tile_off, int32_t* tile_start, int32_t* tile_list, int32_t* info, void* ws,
+                  size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_gauss < 0 || width < 0 || height < 0 || capacity < 1 || capacity > 0x7fffffffLL || !tile_off || !tile_start || !tile_list ||
+      !info || !ws)
+    return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  const int n_tiles = tg.tx * tg.ty;
+  if (n_gauss == 0) {
+    GCP_HIP(hipMemsetAsync(tile_off, 0, sizeof(int), stream));
+    GCP_HIP(hipMemsetAsync(tile_start, 0, (size_t)(n_tiles + 1) * sizeof(int), stream));
+    GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));
+    return GCP_OK;
   }
-  hipLaunchKernelGGL(k_tile_bounds, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256), 0, stream, ks, K, n_tiles,
-                     tile_start);
+  if (!start_xy || !end_xy) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_bin_workspace_bytes(n_gauss, capacity)) return GCP_ERR_WORKSPACE;
+  // count + prefix sum (as gcp_bin_tiles_count, without handing the total to the host); the 64-bit total sits in the
+  // last 256 bytes of the workspace, which the sort buffers never reach (gcp_bin_workspace_bytes adds them)
+  unsigned long long* total64 = (unsigned long long*)((char*)ws + ((ws_bytes - 256) & ~(size_t)255));
+  int* cnt = (int*)((char*)ws + 256);
+  int* sws = (int*)((char*)ws + 256 + align256((size_t)n_gauss * sizeof(int)));
+  GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
+  const i64 count_blocks = (n_gauss + 255) / 256 < 512 ? (n_gauss + 255) / 256 : 512;
+  hipLaunchKernelGGL(k_tile_count, dim3((unsigned)count_blocks), dim3(256), 0, stream, start_xy, end_xy, (i64)n_gauss, width,
+                     height, cnt, total64);
   GCP_HIP(hipGetLastError());
-  return GCP_OK;
+  const int st = launch_excl_scan(cnt, tile_off, n_gauss, sws, stream);
+  if (st != GCP_OK) return st;
+  // (a total beyond int32 wraps tile_off negative, which the emit kernel reads as "does not fit": flagged as overflow)
+  return bin_fill(start_xy, end_xy, n_gauss, width, height, tile_off, capacity, tile_start, tile_list, info, total64, ws, stream);
 }
 
 static int make_args(BlendArgs& a, const int32_t* start_xy, const int32_t* end_xy, const float* mean_xy,
@@ -945,7 +1008,8 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
     GCP_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream,
-                     (const float*)partial, tile_off, vinv, (i64)n_gauss, grad_mean, grad_vinv, grad_opacity, grad_l);
+                     (const float*)partial, tile_off, vinv, (i64)n_gauss, (i64)n_tile_pairs, grad_mean, grad_vinv, grad_opacity,
+                     grad_l);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
@@ -1023,16 +1087,16 @@ int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uin
     unsigned* kd = to_x ? keyX : keyY;
     unsigned* vd = to_x ? valX : valY;
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, (i64)n, shift, hist, (int)nblk);
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, (i64)n, shift, hist, (int)nblk, (const int*)nullptr);
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
     if (st != GCP_OK) return st;
     if (pass == 0)
       hipLaunchKernelGGL((k_sort_scatter<true>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
-                         (const int*)hist_ex, (int)nblk);
+                         (const int*)hist_ex, (int)nblk, (const int*)nullptr);
     else
       hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
-                         (const int*)hist_ex, (int)nblk);
+                         (const int*)hist_ex, (int)nblk, (const int*)nullptr);
     GCP_HIP(hipGetLastError());
     ks = kd;
     vs = vd;

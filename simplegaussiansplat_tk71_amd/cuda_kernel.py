@@ -25,6 +25,8 @@ Deliberate differences from the reference, all result-preserving:
     (:548) uses the int32 permutation directly (gcp_gather_f32).
   * grad_cumsum's flip / scan / flip is one reverse scan on the same sorted keys.
 """
+import contextlib
+
 import torch
 
 from . import grouped_cumprod as _ext
@@ -42,7 +44,42 @@ __all__ = [
     "create_alpha_brend_boxes",
     "grad_cumsum_boxes",
     "custom_autograd_grouped_cumprod",
+    "tile_capacity",
+    "capacity_exceeded",
 ]
+
+# Capture-safe mode of the Function (no device->host read inside forward / backward): the caller bounds the number of
+# (tile, Gaussian) entries of a camera; whether a bound was too small is read back once per step, after the fact.
+_capacity = None
+_pending_info = []
+
+
+@contextlib.contextmanager
+def tile_capacity(n_entries):
+    """Inside this context `custom_autograd_grouped_cumprod.apply` bins with a caller-given bound on the (tile, Gaussian)
+    entry count (about 3 per Gaussian at BASELINE's box sizes; a Gaussian covers ceil(w/16+1) x ceil(h/16+1) tiles at
+    most) instead of reading the exact count back from the device — the reference synchronises on `.item()` per chunk
+    (gs_model.py:677,793,801-802).  Forward and backward then queue their kernels without ever waiting for the GPU and
+    can be captured into a HIP graph.  Pass image_width / image_height as Python ints or CPU tensors (a device tensor
+    would have to be read back).  Call `capacity_exceeded()` once per step."""
+    global _capacity
+    old, _capacity = _capacity, int(n_entries)
+    try:
+        yield
+    finally:
+        _capacity = old
+
+
+def capacity_exceeded():
+    """True if any Function call since the last check ran out of its `tile_capacity` (those calls dropped the Gaussians
+    that did not fit: rerun the step with a larger bound).  One device->host read for all pending calls."""
+    global _pending_info
+    if not _pending_info:
+        return False
+    flags = torch.stack([i[1] for i in _pending_info])
+    _pending_info = []
+    return bool(flags.any().item())
+
 
 
 class GroupedCumprod(torch.autograd.Function):
@@ -207,7 +244,9 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
                 image_height):
         with torch.no_grad():
             w, h = int(image_width), int(image_height)
-            bins = _raster.bin_tiles(startpoint, endpoint, w, h)
+            bins = _raster.bin_tiles(startpoint, endpoint, w, h, capacity=_capacity)
+            if bins.info is not None:
+                _pending_info.append(bins.info)
             image, t_ckpt = _raster.blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d,
                                                   with_checkpoints=True)
         ctx.bins = bins

@@ -48,6 +48,7 @@ class TileBins:
     tile_off: torch.Tensor    # int32[N+1]  first Gaussian-major entry of every Gaussian
     tile_start: torch.Tensor  # int32[n_tiles+1] first sorted entry of every tile
     tile_list: torch.Tensor   # int32[K] Gaussian ids, tile-major, depth order inside a tile
+    info: torch.Tensor = None  # capture-safe mode only: int32[2] on the device = (entries listed, capacity exceeded)
 
     @property
     def tile_capacity(self):
@@ -55,9 +56,18 @@ class TileBins:
         count when the bins were built with the host read of K; the caller's bound in the capture-safe mode)."""
         return self.n_tile_pairs
 
+    def overflowed(self):
+        """Capture-safe mode: True if the capacity was too small (one device->host read; call it once per step, after
+        the work has been queued).  Always False for bins built with the exact count."""
+        return bool(self.info[1].item()) if self.info is not None else False
 
-def bin_tiles(startpoint, endpoint, width, height):
-    """startpoint/endpoint: int [N,2] (x,y) inclusive boxes in depth order."""
+
+def bin_tiles(startpoint, endpoint, width, height, capacity=None):
+    """startpoint/endpoint: int [N,2] (x,y) inclusive boxes in depth order.
+
+    capacity=None: two calls with one device->host read of the entry count K in between (exactly sized buffers).
+    capacity=K_max: ONE call, no read-back, graph-capturable; `bins.n_tile_pairs` is then the capacity, the true count
+    stays on the device (`bins.info`) and `bins.overflowed()` tells after the fact whether the bound was too small."""
     start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
     end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
     n = start.size(0)
@@ -68,6 +78,22 @@ def bin_tiles(startpoint, endpoint, width, height):
     tx, ty = ctypes.c_int32(0), ctypes.c_int32(0)
     _lib.check(lib.gcp_tile_grid(width, height, ctypes.byref(tx), ctypes.byref(ty)), "gcp_tile_grid")
     n_tiles = tx.value * ty.value
+    if capacity is not None:
+        cap = int(capacity)
+        _require(cap >= 1, "capacity: must be >= 1")
+        with torch.cuda.device(dev):
+            tile_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            tile_start = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            tile_list = torch.empty(cap, dtype=torch.int32, device=dev)
+            info = torch.empty(2, dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.gcp_bin_workspace_bytes(n, cap), dtype=torch.uint8, device=dev)
+            _lib.check(
+                lib.gcp_bin_tiles(start.data_ptr(), end.data_ptr(), n, width, height, cap, tile_off.data_ptr(),
+                                  tile_start.data_ptr(), tile_list.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream(dev)),
+                "gcp_bin_tiles",
+            )
+        return TileBins(width, height, n, cap, tx.value, ty.value, tile_off, tile_start, tile_list, info)
     with torch.cuda.device(dev):
         st = _stream(dev)
         tile_off = torch.empty(n + 1, dtype=torch.int32, device=dev)

@@ -481,3 +481,95 @@ def test_random_small_scenes_against_the_dense_oracle(device):
         _close(go, go64, go64.abs().mean().item(), what + " grad_opacity")
         _close(gv, gv64, gv64.abs().mean().item(), what + " grad_vinv")
         _close(gl, gl64, gl64.abs().mean().item(), what + " grad_l")
+
+
+def test_capture_safe_binning_equals_exact_binning_and_reports_overflow(device):
+    """gcp_bin_tiles (one call, caller-bounded entry count, nothing read back) builds the same tile lists as the
+    count / read K / fill route, for any sufficient capacity; a capacity that is too small is reported in `info` and the
+    Gaussians that did not fit are dropped from the BACK of the depth order, with zero gradients."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(700, 120, 90, 14, 31)
+    d = {k: v.to(device) for k, v in sc.items() if isinstance(v, torch.Tensor)}
+    exact = raster.bin_tiles(d["start"], d["end"], 120, 90)
+    K = exact.n_tile_pairs
+    for cap in (K, K + 1, 2 * K + 4097):
+        b = raster.bin_tiles(d["start"], d["end"], 120, 90, capacity=cap)
+        assert b.info.tolist() == [K, 0] and not b.overflowed()
+        assert torch.equal(b.tile_off, exact.tile_off) and torch.equal(b.tile_start, exact.tile_start)
+        assert torch.equal(b.tile_list[:K], exact.tile_list)
+        img_e, ck_e = raster.blend_forward(exact, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], with_checkpoints=True)
+        img_b, ck_b = raster.blend_forward(b, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], with_checkpoints=True)
+        assert torch.equal(img_b, img_e)
+        ge = raster.blend_backward(exact, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], ck_e, d["wimg"])
+        gb = raster.blend_backward(b, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], ck_b, d["wimg"])
+        assert all(torch.equal(x, y) for x, y in zip(gb, ge))
+    # too small: the first Gaussians (front of the depth order) that fit are kept, the rest dropped
+    cap = K // 2
+    b = raster.bin_tiles(d["start"], d["end"], 120, 90, capacity=cap)
+    listed, flag = b.info.tolist()
+    assert flag == 1 and b.overflowed() and 0 < listed <= cap
+    toff = exact.tile_off.cpu()
+    n_kept = int((toff[1:] <= cap).sum())          # Gaussians whose entries end below the capacity
+    assert listed == int(toff[n_kept])
+    part = raster.bin_tiles(d["start"][:n_kept], d["end"][:n_kept], 120, 90)
+    assert torch.equal(b.tile_start, part.tile_start) and torch.equal(b.tile_list[:listed], part.tile_list)
+    img_b, ck_b = raster.blend_forward(b, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], with_checkpoints=True)
+    img_p = raster.blend_forward(part, d["start"][:n_kept], d["end"][:n_kept], d["mean"][:n_kept], d["vinv"][:n_kept],
+                                 d["opacity"][:n_kept], d["l_d"][:n_kept])
+    assert torch.equal(img_b, img_p)
+    gb = raster.blend_backward(b, d["start"], d["end"], d["mean"], d["vinv"], d["opacity"], d["l_d"], ck_b, d["wimg"])
+    assert all(float(g[n_kept:].abs().sum()) == 0.0 for g in gb)
+
+
+def test_function_forward_backward_in_a_hip_graph(device):
+    """With a tile capacity the whole Function — binning, blend forward, blend backward — queues its kernels without a
+    single device->host read, so forward + backward are captured into ONE HIP graph and replayed on new parameter values
+    (the reference synchronises on .item() several times per camera, gs_model.py:677,793,801-802)."""
+    import cuda_kernel as ck
+    from oracle import dense_render as dr
+
+    sc = make_scene(400, 100, 70, 9, 3)
+    n = sc["start"].size(0)
+    st = {k: sc[k].to(device) for k in ("boxsize", "start", "end", "mean")}
+    vinv = sc["vinv"].to(device).clone().requires_grad_(True)
+    op = sc["opacity"].to(device).clone().requires_grad_(True)
+    l_d = sc["l_d"].to(device).clone().requires_grad_(True)
+    wimg = sc["wimg"].to(device)
+    batch = torch.tensor([n], device=device)
+
+    def step():
+        img = ck.custom_autograd_grouped_cumprod.apply(st["boxsize"], batch, st["start"], st["end"], st["mean"], vinv, op, l_d,
+                                                       sc["width"], sc["height"])
+        gv, go, gl = torch.autograd.grad((img * wimg).sum(), (vinv, op, l_d))
+        return img, gv, go, gl
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with ck.tile_capacity(4 * n + 1024), torch.cuda.stream(side):
+        for _ in range(2):
+            step()  # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    assert not ck.capacity_exceeded()
+    graph = torch.cuda.CUDAGraph()
+    with ck.tile_capacity(4 * n + 1024), torch.cuda.graph(graph, stream=side):
+        outs = step()
+    # new parameter values in the captured buffers, then replay: no Python, no host read
+    with torch.no_grad():
+        op.mul_(0.7).add_(0.1)
+        l_d.copy_(torch.rand_like(l_d))
+        vinv.mul_(1.3)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert not ck.capacity_exceeded()
+    img, gv, go, gl = (t.detach().cpu() for t in outs)
+    i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], vinv.detach().cpu(), op.detach().cpu(),
+                                                 l_d.detach().cpu(), sc["width"], sc["height"], sc["wimg"])
+    torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    _close(go, go64, go64.abs().mean().item(), "graph replay grad_opacity")
+    _close(gv, gv64, gv64.abs().mean().item(), "graph replay grad_vinv")
+    _close(gl, gl64, gl64.abs().mean().item(), "graph replay grad_l")
+    # a bound that is too small is reported, not silently wrong
+    with ck.tile_capacity(50):
+        step()
+    assert ck.capacity_exceeded()

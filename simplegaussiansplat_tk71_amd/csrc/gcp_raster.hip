@@ -384,13 +384,14 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
 #define GCP_FP_CONTRACT
 #endif
 
-// Transmittance checkpoints: chunk q of tile t (list entries [first + q kCkpt, first + (q+1) kCkpt)) owns slot
-// first / kCkpt + t + q, 256 floats (one per pixel of the tile, thread order).  Slots of consecutive tiles never
-// overlap (floor(first/c) + ceil(n/c) <= floor((first+n)/c) + 1), so K / kCkpt + n_tiles + 1 slots hold them all
-// without a separate prefix sum.
-__device__ __forceinline__ i64 ckpt_slot0(int first, int tile) { return (i64)(first / kCkpt) + tile; }
+// Transmittance checkpoints: slot q of tile t holds every pixel's transmittance in front of list entry first + q kCkpt,
+// for q = 0 .. ceil(n / kCkpt) — the last one is the transmittance behind the whole list — 256 floats each (one per
+// pixel of the tile, thread order).  Tile t's slots start at first / kCkpt + 2 t: consecutive tiles never overlap
+// (floor(first/c) + ceil(n/c) + 1 <= floor((first+n)/c) + 2), so K / kCkpt + 2 n_tiles + 2 slots hold them all without a
+// separate prefix sum.
+__device__ __forceinline__ i64 ckpt_slot0(int first, int tile) { return (i64)(first / kCkpt) + 2 * (i64)tile; }
 inline size_t ckpt_floats(i64 n_tile_pairs, int n_tiles) {
-  return (size_t)((n_tile_pairs > 0 ? n_tile_pairs : 0) / kCkpt + n_tiles + 1) * 256u;
+  return (size_t)((n_tile_pairs > 0 ? n_tile_pairs : 0) / kCkpt + 2 * (i64)n_tiles + 2) * 256u;
 }
 
 template <bool CKPT>
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
       }
     }
   }
+  if (CKPT) ck[(i64)((last - first + kCkpt - 1) / kCkpt) * 256] = T;  // behind the whole list
   if (px <= a.W && py <= a.H) {
     float* o = image + ((i64)py * (a.W + 1) + px) * 3;
     o[0] = c0; o[1] = c1; o[2] = c2;
@@ -469,11 +471,15 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
 //   dL/do_k    = T_k g_k (c_k - R_k)                 gs_model.py:733-740   (= gp/o - (g/anti) S)
 //   "common"_k = T_k a_k (c_k - R_k)                 gs_model.py:747-748, :757-758   (= gp - (a/anti) S)
 //   dL/dl_k    = dL/dI T_k a_k                       (true gradient; the reference's is channel-collapsed, Q2)
-// The list is walked back to front in chunks of kStageBwd entries; inside a chunk pass A runs front to back from
-// the forward kernel's checkpoint and leaves (T_k, g_k) of every entry in registers (g_k = 0 where the pixel is
-// outside the box or the pair was dropped, gs_model.py:560 — such an entry then contributes exactly nothing below),
-// pass B runs back to front with the recurrence.  No subtraction of accumulated sums, no division: every term is
-// T_k times a convex combination of the c_j, so its round-off is relative to the layer's own transmittance.
+// The list is walked back to front, one staged chunk of kStageBwd entries at a time, in ONE pass: the transmittance in
+// front of an entry comes from the one behind it, T_k = T_{k+1} / (1 - a_k) (v_rcp_f32, 1 ulp), restarted at every chunk
+// from the checkpoint the forward kernel saved for the chunk's END — so the quotients never chain further than one chunk
+// (<= 32 roundings, ~2e-6 relative) and nothing is subtracted or accumulated in T.  A quotient cannot undo an
+// underflow: a chunk in which some pixel's transmittance falls below FLT_MIN (at most one chunk per pixel) is handled by
+// its wave with T_k recomputed front to back from the chunk's START checkpoint for every entry instead (exact, O(32^2 / 2)
+// entry evaluations, no extra registers).  g_k = 0 where the pixel is outside the box or the pair was dropped
+// (gs_model.py:560) — such an entry then contributes exactly nothing.  Every gradient term is T_k times a convex
+// combination of the c_j: its round-off is relative to the layer's own transmittance at any depth.
 __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int* __restrict__ tile_off,
                                                    const float* __restrict__ t_ckpt,
                                                    const float* __restrict__ grad_image,
@@ -513,77 +519,53 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   for (int q = nchunks - 1; q >= 0; --q) {
     const int base = first + q * kStageBwd;
     const int cnt = __builtin_amdgcn_readfirstlane(min(kStageBwd, last - base));  // scalar loop bound
-    float T = 1.0f;
-    if (q > 0) T = ck[(i64)q * 256];  // issued ahead of the staging: its latency hides behind the barrier
+    // transmittance behind this chunk (the next chunk's start, or the end of the list) and in front of it; issued ahead
+    // of the staging: their latency hides behind the barrier
+    const float T_end = ck[(i64)(q + 1) * 256];
+    const float T_start = (q > 0) ? ck[(i64)q * 256] : 1.0f;
     __syncthreads();
     stage_entries<kStageBwd, true>(a, s, base, cnt, ttx * kTile, tty * kTile);
     __syncthreads();
-    // only the entries whose rows reach this wave (the fold below skips this wave's rows for the others, so nothing
-    // needs zeroing).  The wave walks the set bits of its hit word on the scalar unit; the loops are unrolled over the
-    // POSITION j in that walk so that Tk[] / gk[] stay in registers, and the LDS records of the next listed entry are
-    // requested before the current one is evaluated (with three or four waves per SIMD an exposed LDS round trip per
-    // entry costs a third of the kernel).
+    // only the entries whose rows reach this wave, deepest first (the fold below skips this wave's rows for the others,
+    // so nothing needs zeroing)
     const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)s.hits[w][0]);
-    const int nh = __builtin_popcount(hits);
-#ifndef GCP_BWD_SAVE_G
-#define GCP_BWD_SAVE_G 0
-#endif
-    // GCP_BWD_SAVE_G 0 (default): pass B recomputes the kernel value instead of keeping it — 32 VGPRs fewer (four waves
-    // per SIMD instead of three) for 8 more VALU per entry: 0.96 vs 1.06 ms at cfg3.  A dropped / outside pair is then
-    // marked by Tk = 0, which is also what a fully occluded pair has: the same zeros either way.
-    float Tk[kStageBwd];
-    float gk[GCP_BWD_SAVE_G ? kStageBwd : 1];
-    // ---- pass A: front to back, transmittance and kernel value of every entry ----
-    {
-      unsigned h = hits;
-      int k = h ? __builtin_ctz(h) : 0;
-      float4 ge = s.geo[k], vi = s.vin[k];
-#pragma unroll
-      for (int j = 0; j < kStageBwd; ++j) {
-        if (j >= nh) break;  // wave-uniform
-        h &= h - 1;
-        k = h ? __builtin_ctz(h) : 0;
-        const float4 ge_n = s.geo[k], vi_n = s.vin[k];  // next listed entry (entry 0 again after the last: harmless)
+    // wave-uniform: some pixel of the strip underflows inside this chunk — quotients cannot be trusted for it
+    const bool slow = __ballot(T_end < 1.17549435e-38f && T_start != 0.0f) != 0ull;
+    float Tn = T_end;  // transmittance behind the entry in hand
+    unsigned h = hits;
+    while (h) {
+      const int k = 31 - __builtin_clz(h);
+      h &= ~(1u << k);
+      {
+        // straight-line for all 64 lanes; lanes outside the box / dropped pairs are zeroed with selects
+        const float4 ge = s.geo[k];
+        const float4 vi = s.vin[k];
+        const float4 co = s.col[k];
         const bool in = (__float_as_uint(ge.w) & lane_bits) == lane_bits;
         const float dx = fx - ge.x, dy = fy - ge.y;
         // (d Λ) d^T (gs_model.py:495) as a dx^2 + (b + c) dx dy + d dy^2
-        const float g = __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy);
-        const float incl = T * (1.0f - ge.z * g);          // gs_model.py:535, inclusive grouped cumprod
-#if GCP_BWD_SAVE_G
-        Tk[j] = T;
-        gk[j] = (in & (incl != 0.0f)) ? g : 0.0f;          // dropped when the inclusive product is exactly 0 (gs_model.py:560)
-#else
-        Tk[j] = (in & (incl != 0.0f)) ? T : 0.0f;
-#endif
-        T = in ? incl : T;
-        ge = ge_n; vi = vi_n;
-      }
-    }
-    // ---- pass B: back to front, gradients ----
-    {
-      unsigned h = hits;
-      int k = h ? 31 - __builtin_clz(h) : 0;
-      float4 ge = s.geo[k], co = s.col[k];
-#if !GCP_BWD_SAVE_G
-      float4 vi = s.vin[k];
-#endif
-#pragma unroll
-      for (int j = kStageBwd - 1; j >= 0; --j) {
-        if (j < nh) {  // wave-uniform; the bodies above the list length are skipped once per chunk
-        const int kc = k;
-        h &= ~(1u << kc);
-        k = h ? 31 - __builtin_clz(h) : 0;
-        const float4 ge_n = s.geo[k], co_n = s.col[k];
-        const float dx = fx - ge.x;
-#if GCP_BWD_SAVE_G
-        const float gv = gk[j];
-#else
-        const float4 vi_n = s.vin[k];
-        const float dy = fy - ge.y;
-        const float gv = (Tk[j] != 0.0f) ? __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy) : 0.0f;
-        vi = vi_n;
-#endif
-        const float tg = Tk[j] * gv;
+        const float gv = __builtin_amdgcn_exp2f(dx * (vi.x * dx + vi.y * dy) + (vi.z * dy) * dy);
+        const float og = ge.z * gv;
+        const float anti = 1.0f - og;                       // gs_model.py:535
+        float Tk, incl;
+        if (!slow) {
+          incl = Tn;                                          // what the forward pass left behind this pair
+          Tk = (Tn == 0.0f) ? 0.0f : Tn * __builtin_amdgcn_rcpf(anti);
+        } else {
+          Tk = T_start;
+          for (unsigned hh = hits & ((1u << k) - 1u); hh; hh &= hh - 1) {
+            const int j = __builtin_ctz(hh);
+            const float4 gj = s.geo[j];
+            const float4 vj = s.vin[j];
+            const float dxj = fx - gj.x, dyj = fy - gj.y;
+            const float g_j = __builtin_amdgcn_exp2f(dxj * (vj.x * dxj + vj.y * dyj) + (vj.z * dyj) * dyj);
+            Tk = ((__float_as_uint(gj.w) & lane_bits) == lane_bits) ? Tk * (1.0f - gj.z * g_j) : Tk;
+          }
+          incl = Tk * anti;
+        }
+        const bool keep = in & (incl != 0.0f);                // dropped when the inclusive product is exactly 0 (gs_model.py:560)
+        Tn = in ? Tk : Tn;
+        const float tg = keep ? Tk * gv : 0.0f;
         const float c = g0 * co.x + g1 * co.y + g2 * co.z;   // dL/dI . l
         const float d = c - R;
         float r_o = tg * d;
@@ -592,8 +574,8 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         float r_l0 = g0 * wgt, r_l1 = g1 * wgt, r_l2 = g2 * wgt;
         float r_cx = r_c * dx;
         float r_xx = r_cx * dx;
-        R = R + (ge.z * gv) * d;                                // R_{k-1} = R_k + a_k (c_k - R_k)
-        ge = ge_n; co = co_n;
+        R = keep ? R + og * d : R;                              // R_{k-1} = R_k + a_k (c_k - R_k)
+        const int kc = k;
         // Seven 16-lane row sums by a transposed butterfly: at each step a lane keeps half of its values and hands the
         // other half to its partner, so the live registers halve.  Partners: 15-i, 7-i (within each half), i^2, i^1;
         // afterwards lane i holds the row sum of value ((i>>1)&1)*4 + ((i>>2)&1)*2 + ((i>>3)&1) (slot 7 is a dummy).
@@ -633,7 +615,6 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
         const float o0 = xchg_sum<0x4e>(b1, p0, p1);
         const float tot = o0 + dpp_f<0xb1, 0xf>(0.0f, o0);
         row_slot[kc * kPartStride] = tot;  // lanes i and i^1 store the same word
-        }
       }
     }
     __syncthreads();

@@ -107,8 +107,8 @@ def test_raster_argument_validation_needs_no_gpu():
     assert lib.gcp_bin_workspace_bytes(1000, 3000) % 256 == 0
     assert lib.gcp_bin_workspace_bytes(1_000_000, 3_000_000) < 64 << 20
     assert lib.gcp_blend_backward_workspace_bytes(3_000_000) == 3_000_000 * 9 * 4  # 9 floats per (tile, Gaussian) entry
-    # one transmittance per pixel of a tile per 32 list entries: K / 32 + n_tiles + 1 slots of 256 floats
-    assert lib.gcp_blend_checkpoint_floats(3_000_000, 1919, 1079) == (3_000_000 // 32 + 120 * 68 + 1) * 256
+    # one transmittance per pixel of a tile per 32 list entries: K / 32 + 2 n_tiles + 2 slots (one per 32 entries, plus the end of every list) of 256 floats
+    assert lib.gcp_blend_checkpoint_floats(3_000_000, 1919, 1079) == (3_000_000 // 32 + 2 * 120 * 68 + 2) * 256
     k = ctypes.c_int64(-1)
     assert lib.gcp_bin_tiles_count(None, None, -1, 10, 10, None, ctypes.byref(k), None, 0, None) == 1
     assert lib.gcp_blend_forward(None, None, None, None, None, None, 5, 10, 10, None, None, None, None, None) == 1

@@ -85,7 +85,8 @@ constexpr int kTile = 1024 * kRows;
 #endif
 constexpr int kLbBatch = GCP_LB_BATCH;  // look-back chunks fetched per dependent round trip after the first
 constexpr int kLbChunks = ((kTile / 256 - 1) / kLbBatch) * kLbBatch + 1;  // window in 256-element chunks (16 = one tile at kRows 4)
-constexpr int kFixBlocks = 256;     // upper bound of the fallback kernel's grid
+constexpr int kFixBlocks = 256;     // upper bound of the fallback kernel's grid (two-pass mode)
+constexpr int kFixBlocksQuiet = 32; // ... when the descriptor tree is on and the kernel normally finds nothing to do
 constexpr int kWsHeaderBytes = 256;
 // workspace header words
 constexpr int kHdrEpoch = 0;        // launches completed on this workspace; its parity selects the descriptor set
@@ -995,7 +996,11 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   }
   GCP_HIP(hipGetLastError());
   if (ntiles > 1) {
-    const unsigned fb = (unsigned)(ntiles < kFixBlocks ? ntiles : kFixBlocks);
+    // the follow-up kernel: a no-op walk over the tile descriptors unless a tile gave up waiting.  Every block ends
+    // with one atomic on the same word (the last one advances the launch counter): 256 of them cost 7 us, so the
+    // grid is small unless the descriptor walk is switched off and the kernel has real work on every long group
+    const i64 want = a.patience < 0 ? kFixBlocks : kFixBlocksQuiet;
+    const unsigned fb = (unsigned)(ntiles < want ? ntiles : want);
     hipLaunchKernelGGL((gcp_fallback<MODE>), dim3(fb), dim3(kThreads), 0, stream, a);
     GCP_HIP(hipGetLastError());
   }

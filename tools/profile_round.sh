@@ -1,18 +1,25 @@
 #!/bin/bash
-# Collect one round's rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r01'
-# then, locally:  python tools/summarize_profiles.py gpurun_out/r01 r01
-# Kernel trace + stats in one run; FETCH_SIZE and WRITE_SIZE in two separate --pmc runs (never combined with traces).
-set -e -o pipefail
-TAG=${1:-r01}
-R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/$TAG
-rm -rf "$OUT" && mkdir -p "$OUT"
+# Collect one round's rocprofv3 evidence on the GPU box (run through gpurun), then condense it with
+# tools/summarize_profiles.py into profiles/ (tracked):
+#   gpurun --timeout 1100 -- 'tools/profile_round.sh r02'
+# Counter passes are separate runs with --pmc only (no trace domains besides --kernel-trace), the program itself after `--`.
+set -e
+TAG=$1
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+rm -rf $OUT && mkdir -p $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/long_fetch $OUT/long_write $OUT/fn_pmc $OUT/fn_stats
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 python3 $R/bench.py > $OUT/bench_plain.json 2> $OUT/plain.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py > $OUT/bench_stats.json 2> $OUT/stats.err
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT/bench_fetch.json 2> $OUT/fetch.err
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT/bench_write.json 2> $OUT/write.err
-# keep what the summariser needs, drop the bulky per-dispatch traces (gpurun_out/ merges back at most 64 MiB)
-find $OUT -name "*kernel_trace.csv" -delete
-du -sh $OUT
+echo "== plain bench"; python3 $ROOT/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+echo "== kernel trace + stats of bench.py"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $ROOT/bench.py --cpu-sample 0 > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+export GCP_BENCH_NO_SHARDED=1
+echo "== pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $ROOT/bench.py --cpu-sample 0 --steps 20 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "== pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $ROOT/bench.py --cpu-sample 0 --steps 20 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "== long groups: timing, then traffic"
+python3 $ROOT/tools/pathological_bench.py > $OUT/long_groups.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/long_fetch -o p --output-format csv -- python3 $ROOT/tools/pathological_bench.py "whole array" "5000" > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/long_write -o p --output-format csv -- python3 $ROOT/tools/pathological_bench.py "whole array" "5000" > /dev/null 2>&1
+echo "== Function kernels: stats, then SQ counters"
+rocprofv3 --kernel-trace --stats -d $OUT/fn_stats -o st --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > $OUT/fn_bench.txt 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d $OUT/fn_pmc -o p --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > /dev/null 2>&1
+echo "== done"; ls $OUT

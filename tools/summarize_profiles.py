@@ -44,14 +44,31 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     stats = max(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-    rows = list(csv.DictReader(open(stats)))
-    # the library's kernels: the scans (gcp_*) and, from bench.py's function_level / caller_level legs, k_* (binning,
-    # blend, sort, projection, loss)
-    ours = [r for r in rows if "gcp_" in r["Name"] or "::k_" in r["Name"]]
+    raw = list(csv.DictReader(open(stats)))
+    with open(os.path.join(out, f"{tag}_kernel_stats_raw.csv"), "w", newline="") as f:  # rocprofv3's own --stats rows, ours only
+        w = csv.DictWriter(f, fieldnames=raw[0].keys())
+        w.writeheader()
+        w.writerows([r for r in raw if "gcp_" in r["Name"] or "::k_" in r["Name"]])
+    # bench.py launches the same kernels on several workloads (the timed cfg3 list, the unclipped variant, the cfg5 / cfg3
+    # sharded frames): --stats averages over all of them, so the rows below are re-aggregated from the kernel trace PER
+    # GRID SIZE (= tiles of the launch)
+    trace = max(glob.glob(os.path.join(src, "stats", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    groups = collections.OrderedDict()
+    for r in csv.DictReader(open(trace)):
+        if "gcp_" not in r["Kernel_Name"] and "::k_" not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))
+        groups.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows = []
+    for (name, blocks), d in groups.items():
+        rows.append({"Name": name, "Blocks": blocks, "Calls": len(d), "TotalDurationNs": sum(d), "AverageNs": sum(d) / len(d),
+                     "MinNs": min(d), "MaxNs": max(d)})
+    rows.sort(key=lambda r: -r["TotalDurationNs"])
+    ours = rows
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys())
         w.writeheader()
-        w.writerows(ours)
+        w.writerows(rows)
     bench = json.loads(open(os.path.join(src, "bench_stats.json")).read().strip().splitlines()[-1])
     plain = None
     if os.path.exists(os.path.join(src, "bench_plain.json")):
@@ -59,14 +76,25 @@ def main():
     m = bench["config"]["pairs_per_gpu"]
     fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
     traffic = {}
-    lines = [f"# {tag}: rocprofv3 summary of `python3 bench.py` (cfg3, M = {m} pairs)", "",
+    lines = [f"# {tag}: rocprofv3 summary of `python3 bench.py` (cfg3, M = {m} pairs = {(m + 4095) // 4096} tiles)", "",
+             "Rows are aggregated from the kernel trace per (kernel, grid size): the headline's timed region is the "
+             f"{(m + 4095) // 4096}-tile launches of cumprod_fwd / cumprod_bwd; the other sizes of the same kernels belong to the "
+             "`unclipped` and `sharded_frames` blocks of the same command (rocprofv3's own --stats rows, which average over all of "
+             f"them, are in {tag}_kernel_stats_raw.csv).  PMC traffic is from the separate --pmc passes, averaged over the launches "
+             "of those passes (GCP_BENCH_NO_SHARDED=1: the timed workload and its unclipped twin, same size within 0.01 %).", "",
              "| kernel | calls | avg us (rocprof) | algorithmic B/launch | algorithmic GB/s | FETCH_SIZE KiB (raw) | "
              "WRITE_SIZE KiB | HBM bytes/launch (2*FETCH+WRITE) | traffic / algorithmic | HBM GB/s |",
              "|---|---|---|---|---|---|---|---|---|---|"]
     per = {"cumprod_fwd": 12, "cumprod_bwd": 20, "cumsum_fwd": 12, "cumsum_rev": 12}
+    tile = 4096
+    headline_blocks = (m + tile - 1) // tile
     for r in ours:
         s = short(r["Name"])
         avg_us = float(r["AverageNs"]) / 1e3
+        if s in per and r["Blocks"] != headline_blocks:
+            lines.append(f"| {s} ({r['Blocks']} tiles: another workload of the same run) | {r['Calls']} | {avg_us:.1f} | - | "
+                         f"{per[s] * r['Blocks'] * tile / avg_us / 1e3:.0f} (upper bound: last tile partial) | - | - | - | - | - |")
+            continue
         if s in per:
             alg = per[s] * m
             hb = None
@@ -78,7 +106,8 @@ def main():
                          f"{write.get(s, float('nan')):.0f} | {hb if hb else 'n/a':.4g} | {hb/alg if hb else float('nan'):.3f} | "
                          f"{hb/avg_us/1e3 if hb else float('nan'):.0f} |")
         else:
-            lines.append(f"| {s} | {r['Calls']} | {avg_us:.2f} | - | - | {fetch.get(s, 0):.1f} | {write.get(s, 0):.1f} | - | - | - |")
+            name = s or r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]
+            lines.append(f"| {name} | {r['Calls']} | {avg_us:.2f} | - | - | {fetch.get(s, 0):.1f} | {write.get(s, 0):.1f} | - | - | - |")
     lines += ["", "bench.py under the profiler (HIP events on the launch stream, op = main kernel + fallback launch):", "",
               "```", json.dumps({k: bench[k] for k in ("value", "ms_per_step")}),
               json.dumps(bench["roofline"]), "```"]
@@ -92,6 +121,88 @@ def main():
     allt["cfg3"] = traffic
     allt["_source"] = f"{tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py (separate runs); reads doubled per the gfx950 correction"
     json.dump(allt, open(path, "w"), indent=1)
+    print("\n".join(lines))
+    long_groups(src, tag, out)
+    function_kernels(src, tag, out)
+
+
+def per_launch(dirname, counter, pick):
+    """kernel -> list of per-launch values of `counter` in launch order, newest run of `dirname`."""
+    acc = collections.defaultdict(list)
+    files = sorted(glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            k = pick(r["Kernel_Name"])
+            if k and r["Counter_Name"] == counter:
+                acc[k].append(float(r["Counter_Value"]))
+    return acc
+
+
+def long_groups(src, tag, out):
+    """Traffic of the scans on inputs whose groups are far longer than a tile (tools/pathological_bench.py "whole array"
+    "5000": two cases x two modes, forward scans then backward scans per case; 14 launches of each per case)."""
+    if not os.path.isdir(os.path.join(src, "long_fetch")):
+        return
+    n = 166_000_000
+    fetch = per_launch(os.path.join(src, "long_fetch"), "FETCH_SIZE", short)
+    write = per_launch(os.path.join(src, "long_write"), "WRITE_SIZE", short)
+    lines = [f"# {tag}: scans on groups far longer than one tile (n = {n}, tools/pathological_bench.py)", "",
+             "Timing (same script, no profiler):", "", "```",
+             *[ln for ln in open(os.path.join(src, "long_groups.txt")).read().splitlines() if "amdgpu.ids" not in ln], "```", "",
+             "HBM traffic per launch from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (reads = 2 x FETCH_SIZE "
+             "KiB x 1024 on gfx950, writes = WRITE_SIZE KiB x 1024); launches in order: case 'one group = whole array' then "
+             "'groups of 5000-13000', first with the descriptor tree (main kernel does everything, the follow-up kernel is a "
+             "no-op), then with the walk switched off (two-pass: the follow-up kernel re-reads and re-writes the leading "
+             "elements of every unresolved tile).", "",
+             "| kernel | mode | case | launches | HBM bytes / launch | algorithmic bytes | traffic / algorithmic |", "|---|---|---|---|---|---|---|"]
+    per = {"cumprod_fwd": 12, "cumprod_bwd": 20}
+    fb = {"cumprod_fwd": "fallback_fwd", "cumprod_bwd": "fallback_bwd"}
+    for k, bpe in per.items():
+        f, w = fetch.get(k, []), write.get(k, [])
+        ff, wf = fetch.get(fb[k], []), write.get(fb[k], [])
+        if not f or len(f) != len(w) or len(f) % 4:
+            continue
+        q = len(f) // 4
+        for i, (mode, case) in enumerate((("tree", "one group"), ("tree", "groups 5-13k"), ("two-pass", "one group"), ("two-pass", "groups 5-13k"))):
+            hb = sum((2 * a + b) * 1024 for a, b in zip(f[i * q:(i + 1) * q], w[i * q:(i + 1) * q])) / q
+            hf = sum((2 * a + b) * 1024 for a, b in zip(ff[i * q:(i + 1) * q], wf[i * q:(i + 1) * q])) / q if len(ff) == len(f) else float("nan")
+            lines.append(f"| {k} + follow-up | {mode} | {case} | {q} | {hb:.4g} + {hf:.3g} | {bpe * n:.4g} | {(hb + hf) / (bpe * n):.3f} |")
+    open(os.path.join(out, f"{tag}_long_groups.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+def function_kernels(src, tag, out):
+    """Per-kernel durations and SQ counters of the Function's kernels (tools/raster_bench.py, cfg3 scene)."""
+    if not os.path.isdir(os.path.join(src, "fn_pmc")):
+        return
+    pick = lambda k: next((n for n in ("k_blend_bwd", "k_blend_fwd<true>", "k_blend_fwd<false>", "k_grad_reduce") if n in k), None)  # noqa: E731
+    counters = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
+                "SQ_INSTS_LDS", "SQ_INSTS_SALU"]
+    vals = {c: {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "fn_pmc"), c, pick).items()} for c in counters}
+    stats = max(glob.glob(os.path.join(src, "fn_stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    dur = {}
+    for r in csv.DictReader(open(stats)):
+        k = pick(r["Name"])
+        if k:
+            dur[k] = float(r["AverageNs"]) / 1e3
+    lines = [f"# {tag}: the Function's kernels on the cfg3 scene (1920x1080, 10^6 Gaussians, 1.65e8 pairs, 3.0e6 tile entries)", "",
+             "`rocprofv3 --kernel-trace --stats` and a separate `--pmc` pass of `python3 tools/raster_bench.py --no-cameras`; counters are "
+             "per launch, summed over the chip; the *_CYCLES / WAIT / ACTIVE ones count quad-cycles per wave.", "",
+             "| kernel | avg us | " + " | ".join(counters) + " | VALU issue time at 1024 SIMDs x 2.4 GHz / 4 (us) |", "|---|---|" + "---|" * (len(counters) + 1)]
+    pj = {}
+    for k in dur:
+        row = [f"{vals[c].get(k, float('nan')):.4g}" for c in counters]
+        iv = vals["SQ_INSTS_VALU"].get(k)
+        lines.append(f"| {k} | {dur[k]:.1f} | " + " | ".join(row) + f" | {iv / (1024 * 2.4e9 / 4) * 1e6 if iv else float('nan'):.0f} |")
+        pj[k] = {c: vals[c].get(k) for c in counters}
+        pj[k]["avg_us_rocprof"] = dur[k]
+    keep = [ln for ln in open(os.path.join(src, "fn_bench.txt")).read().splitlines()
+            if ln.strip() and "rocprofv3" not in ln and not ln.startswith(("W2", "E2", "I2")) and "amdgpu.ids" not in ln]
+    lines += ["", "```", *keep, "```"]
+    open(os.path.join(out, f"{tag}_function_kernels.md"), "w").write("\n".join(lines) + "\n")
+    path = os.path.join(out, "pmc_function.json")
+    json.dump({"cfg3": pj, "_source": f"{tag}: rocprofv3 --pmc (SQ counters) pass of tools/raster_bench.py"}, open(path, "w"), indent=1)
     print("\n".join(lines))
 
 

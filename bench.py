@@ -173,13 +173,18 @@ def function_level(dev, workload):
     _, t_bwd = timed(lambda: raster.blend_backward(bins, *params, ckpt, gimg))
     visits, lane_frac = lane_use(bins, sc["start"], sc["end"])
     insts = pmc_function("k_blend_bwd", workload, "SQ_INSTS_VALU")
+    kernel_us = pmc_function("k_blend_bwd", workload, "avg_us_rocprof")  # the kernel alone, same committed profile
     roof = {
         "kernel": "k_blend_bwd (fused blend backward; HBM traffic is K x 64 B + checkpoints + image: far from the HBM roof)",
         "bound": "valu-issue",
         "insts": insts,  # VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, profiles/pmc_function.json)
         "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
+        # live: HIP events around raster.blend_backward = k_blend_bwd + k_grad_reduce + the host call
         "achieved_wave_insts_per_s": None if insts is None else insts / (t_bwd * 1e-3),
         "frac": None if insts is None else insts / (t_bwd * 1e-3) / VALU_PEAK_WAVE_INSTS,
+        # the kernel alone, from the committed rocprofv3 pass (profiles/r02_function_kernels.md)
+        "kernel_us_rocprof": kernel_us,
+        "frac_kernel_alone": None if insts is None or not kernel_us else insts / (kernel_us * 1e-6) / VALU_PEAK_WAVE_INSTS,
         "wave_entry_visits": visits,
         "valu_per_visit": None if insts is None or not visits else insts / visits,
         "active_lane_frac": lane_frac,  # pixels inside the visited entry's box / 64 lanes issued

@@ -471,7 +471,16 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         return !more;             // reached the end of the array: resolved
       };
       bool done = process(lbv, lbk, lbp, 0);
-      for (int j = 1; !done && j < kLbChunks; j += kLbBatch) {
+      // A group that already spans the 256 elements behind the tile AND this wave's whole 1024-element share is long:
+      // stop reading raw inputs (up to three more dependent round trips that would most likely end at the window's
+      // edge) and take the carry from the descriptor tree.  A data-determined rule, so still deterministic.
+#ifndef GCP_LB_EARLY_EXIT
+#define GCP_LB_EARLY_EXIT 1
+#endif
+      bool wave_headless = GCP_LB_EARLY_EXIT != 0;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) wave_headless = wave_headless && (hmask[r] == 0ull);
+      for (int j = 1; !done && !wave_headless && j < kLbChunks; j += kLbBatch) {
         float4_t cv[kLbBatch];
         int4_t ck[kLbBatch];
         i64 cp[kLbBatch];

@@ -362,6 +362,43 @@ def test_hip_graph_capture_and_replay(device):
     assert_parity(g, co.cumprod_backward_f64(x2, want_y, go.cpu(), inv).float(), scale, "graph replay backward")
 
 
+def test_descriptor_tree_levels_exact_integers(device):
+    """Groups of 3e5 .. 9e5 elements and one of 1.6e7 over 4 915 tiles: every tile's carry comes from the radix-64
+    descriptor tree, across level-1 (64 tiles) and level-2 (4 096 tiles) block boundaries.  Sums of ones are exact
+    integers in fp32 whatever the association, so any structural slip of the tree shows as a wrong integer."""
+    import grouped_cumprod as gc
+
+    n = 4915 * gc.tile_elems() + 777
+    g = torch.Generator(device=device).manual_seed(4)
+    lens = torch.randint(300_000, 900_000, (n // 300_000 + 2,), device=device, generator=g)
+    lens[2] = 16_000_000  # < 2^24: positions stay exact
+    ids = torch.arange(lens.numel(), device=device, dtype=torch.int32)
+    key = torch.repeat_interleave(ids, lens)[:n].contiguous()
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(lens, 0)[:-1]])
+    ends = torch.minimum(torch.cumsum(lens, 0), torch.tensor(n, device=device))
+    idx = torch.arange(n, device=device)
+    ones = torch.ones(n, device=device)
+    out = torch.empty(n, device=device)
+    gc.grouped_cumsum_forward(ones, key, out)
+    assert gc.last_fallback_tiles(device) == 0 and gc.last_lookback_tiles(device) > 4000
+    assert torch.equal(out, (idx - starts[key.long()] + 1).float())
+    gc.grouped_cumsum_reverse(ones, key, out)
+    assert torch.equal(out, (ends[key.long()] - idx).float())
+    gc.grouped_cumprod_backward(ones, ones, ones, key, out, torch.zeros(1, dtype=torch.int32, device=device))
+    assert torch.equal(out, (ends[key.long()] - idx).float())
+    # products: 2^-k exact as long as it stays normal or denormal; restart the exponent every 100 elements with a 2^99 factor
+    x = torch.full((n,), 0.5, device=device)
+    x[idx % 100 == 0] = float(2.0 ** 99)
+    x[starts[starts < n]] = 0.5
+    gc.grouped_cumprod_forward(x, key, out)
+    pos = idx - starts[key.long()]                      # 0-based position in the group
+    # number of boosted elements in (start, idx]: absolute multiples of 100 in that range (a group's first element is 0.5)
+    nboost = idx // 100 - starts[key.long()] // 100
+    expo = -(pos + 1 - nboost) + 99 * nboost
+    want = torch.pow(torch.tensor(2.0, dtype=torch.float64, device=device), expo.double()).float()
+    assert torch.equal(out, want)
+
+
 def test_more_than_2_31_elements(device):
     """Maximum sizes: the reference takes n as `int` (grouped_cumprod_backward.cu:52); here every array index is
     64-bit.  n = 2^31 + 12296 elements (8.6 GB per array), groups of 1000, exact integer results."""
@@ -393,3 +430,15 @@ def test_more_than_2_31_elements(device):
     for lo in (0, (1 << 31) - 3000, n - 3000):
         idx = torch.arange(lo, lo + 3000, device=device)
         assert torch.equal(out[idx], table[(idx % L) + 1])
+    # the same size with groups of 5e6 elements: 524 291 tiles, nearly all head-less — their carries run through all
+    # four levels of the descriptor tree (level 3 = blocks of 262 144 tiles); exact integer sums
+    del half, key
+    L2 = 5_000_000
+    key = (torch.arange(n, device=device) // L2).to(torch.int32)
+    gc.grouped_cumsum_forward(ones, key, out)
+    assert gc.last_fallback_tiles(device) == 0 and gc.last_lookback_tiles(device) > 500_000
+    for lo in (0, L2 - 1500, (1 << 31) - 3000, n - 3000):
+        idx = torch.arange(lo, lo + 3000, device=device)
+        assert torch.equal(out[idx], ((idx % L2) + 1).float())
+    chk = out[:: 4097]  # a strided sample over the whole array
+    assert torch.equal(chk, ((torch.arange(0, n, 4097, device=device) % L2) + 1).float())

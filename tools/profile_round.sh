@@ -21,5 +21,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/long_fetch -o p --output-forma
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/long_write -o p --output-format csv -- python3 $ROOT/tools/pathological_bench.py "whole array" "5000" > /dev/null 2>&1
 echo "== Function kernels: stats, then SQ counters"
 rocprofv3 --kernel-trace --stats -d $OUT/fn_stats -o st --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > $OUT/fn_bench.txt 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d $OUT/fn_pmc -o p --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/fn_pmc -o p --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > /dev/null 2>&1
 echo "== done"; ls $OUT

@@ -178,7 +178,7 @@ def function_kernels(src, tag, out):
         return
     pick = lambda k: next((n for n in ("k_blend_bwd", "k_blend_fwd<true>", "k_blend_fwd<false>", "k_grad_reduce") if n in k), None)  # noqa: E731
     counters = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU",
-                "SQ_INSTS_LDS", "SQ_INSTS_SALU"]
+                "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"]
     vals = {c: {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "fn_pmc"), c, pick).items()} for c in counters}
     stats = max(glob.glob(os.path.join(src, "fn_stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     dur = {}
@@ -199,7 +199,12 @@ def function_kernels(src, tag, out):
         pj[k]["avg_us_rocprof"] = dur[k]
     keep = [ln for ln in open(os.path.join(src, "fn_bench.txt")).read().splitlines()
             if ln.strip() and "rocprofv3" not in ln and not ln.startswith(("W2", "E2", "I2")) and "amdgpu.ids" not in ln]
-    lines += ["", "```", *keep, "```"]
+    lanes = {k: (vals["SQ_THREAD_CYCLES_VALU"].get(k) or 0) / max(vals["SQ_INSTS_VALU"].get(k) or 1, 1) for k in dur}
+    lines += ["", "SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = lanes ENABLED per VALU instruction (of 64): "
+              + ", ".join(f"{k} {v:.1f}" for k, v in lanes.items()) + ".  The backward's body is branch-free (selects), so "
+              "nearly all lanes are enabled whether or not their pixel lies in the entry's box; the forward masks with exec.  "
+              "Neither says how many lanes did USEFUL work: that fraction (pixels inside the visited entry's box) is computed from "
+              "the tile lists by bench.py (function_level.roofline.active_lane_frac = 0.375 on this scene).", "", "```", *keep, "```"]
     open(os.path.join(out, f"{tag}_function_kernels.md"), "w").write("\n".join(lines) + "\n")
     path = os.path.join(out, "pmc_function.json")
     json.dump({"cfg3": pj, "_source": f"{tag}: rocprofv3 --pmc (SQ counters) pass of tools/raster_bench.py"}, open(path, "w"), indent=1)

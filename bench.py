@@ -264,7 +264,21 @@ def sharded_frame(name, world, rank, device, scan_fwd_bwd, sync, steps=10, warmu
     from simplegaussiansplat_tk71_amd import sharding, synthetic
 
     kw = {} if max_run is None else {"max_run": max_run}
-    p, shards, total_pairs = synthetic.make_config_slice(name, world, rank, seed=0, device=device, **kw)
+    # build this rank's slice; if ANY rank fails here (out of memory, ...) every rank skips the block together — a rank
+    # that raised on its own would leave the others waiting in the next collective
+    p = shards = None
+    total_pairs, fail = 0, None
+    try:
+        p, shards, total_pairs = synthetic.make_config_slice(name, world, rank, seed=0, device=device, **kw)
+    except Exception as e:  # noqa: BLE001 - reported in the JSON line
+        fail = repr(e)
+    if world > 1:
+        ok = torch.tensor([0.0 if fail else 1.0], dtype=torch.float64, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            return {"workload": name, "skipped": fail or "another rank failed to build its slice"}
+    elif fail:
+        return {"workload": name, "skipped": fail}
     for _ in range(warmup):
         scan_fwd_bwd(p)
     sync()
@@ -465,8 +479,11 @@ def main():
             free, _ = torch.cuda.mem_get_info(dev)
             c = synthetic.CONFIGS[name]
             est = c["height"] * c["width"] * c["mean_depth"] / world * 4 * 12  # slice arrays + generation temporaries
-            if free < est:
-                sharded[name] = {"skipped": f"needs ~{est / 2**30:.0f} GiB of HBM per rank, {free / 2**30:.0f} GiB free"}
+            enough = torch.tensor([1.0 if free >= est else 0.0], dtype=torch.float64, device=dev)
+            if world > 1:  # the decision must be the same on every rank: the block contains collectives
+                dist.all_reduce(enough, op=dist.ReduceOp.MIN)
+            if float(enough.item()) == 0.0:
+                sharded[name] = {"skipped": f"needs ~{est / 2**30:.0f} GiB of HBM per rank, {free / 2**30:.0f} GiB free on rank {rank}"}
                 continue
             sharded[name] = sharded_frame(name, world, rank, dev, scan_fwd_bwd, sync, steps=10, warmup=3,
                                           collectives=os.environ.get("GCP_BENCH_NO_COLLECTIVES", "0") != "1")

@@ -19,11 +19,13 @@
 //       Backward walks each tile list BACK TO FRONT in chunks of kStageBwd entries: the exclusive suffix
 //       sum S_k of (dL/dI . p) the reference gets from a flipped grouped cumsum (gs_model.py:716-722)
 //       is carried in the normalised form S_k / (1 - o_k g_k) = T_k * R_k with the recurrence
-//       R_{k-1} = R_k + o_k g_k ((dL/dI . l_k) - R_k)  — a convex combination, no cancellation, no
-//       division — and T_k (the exclusive transmittance) comes from a front-to-back pass over the
-//       chunk that starts from the per-chunk checkpoint the forward kernel saved (T per pixel every
-//       kStageBwd entries).  Every gradient term is T_k times a bounded quantity, so its round-off is
-//       relative to the transmittance of ITS OWN layer whatever the depth.
+//       R_{k-1} = R_k + o_k g_k ((dL/dI . l_k) - R_k)  — a convex combination: no accumulated sum is
+//       subtracted — and T_k (the exclusive transmittance) comes from the entry behind it,
+//       T_k = T_{k+1} / (1 - o_k g_k), restarted at every chunk from the checkpoint the forward kernel
+//       saved for the chunk's end (T per pixel every kStageBwd entries, and behind the whole list); the
+//       one chunk per pixel in which T underflows is recomputed front to back instead.  Every gradient
+//       term is T_k times a bounded quantity, so its round-off is relative to the transmittance of
+//       ITS OWN layer whatever the depth.
 //       Per-pair gradients collapse to 7 per-lane values;
 //       they are summed along each pixel row of the tile (16 lanes = one DPP row, 4 fused
 //       v_add_f32_dpp) into LDS, one thread per entry folds the 16 rows (dy is constant along a

@@ -109,6 +109,9 @@ constexpr int kXcdChunk = GCP_XCD_CHUNK;  // consecutive tiles one XCD takes bef
 #ifndef GCP_DESC_WAIT_US
 #define GCP_DESC_WAIT_US 200
 #endif
+#ifndef GCP_LB_EARLY_EXIT
+#define GCP_LB_EARLY_EXIT 1      // leave the raw look-back after its first chunk when wave 0's whole share is head-less (§3.1 of DESIGN.md)
+#endif
 
 static_assert(kLbChunks * 256 == kTile, "the raw look-back window is exactly the previous tile (the descriptor walk starts at the tile before it)");
 static_assert((kLbChunks - 1) % kLbBatch == 0, "chunks after the first are fetched kLbBatch at a time");
@@ -474,9 +477,6 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       // A group that already spans the 256 elements behind the tile AND this wave's whole 1024-element share is long:
       // stop reading raw inputs (up to three more dependent round trips that would most likely end at the window's
       // edge) and take the carry from the descriptor tree.  A data-determined rule, so still deterministic.
-#ifndef GCP_LB_EARLY_EXIT
-#define GCP_LB_EARLY_EXIT 1
-#endif
       bool wave_headless = GCP_LB_EARLY_EXIT != 0;
 #pragma unroll
       for (int r = 0; r < kRows; ++r) wave_headless = wave_headless && (hmask[r] == 0ull);
@@ -687,7 +687,9 @@ void gcp_scan_main(const ScanArgs a) {
 }
 
 // ----------------------------------------------------------------------------
-// Fallback kernel (one launch after every multi-tile scan).  Block b owns the
+// Follow-up ("fallback") kernel, one small launch after every multi-tile scan: finishes the
+// tiles whose wait for the descriptor tree ran out (none in practice; all long-group tiles in
+// two-pass mode) and maintains the workspace.  Block b owns the
 // contiguous tile range [b*per, (b+1)*per).  Common case: no tile of the range
 // is unresolved -> one coalesced descriptor read and return.  Otherwise wave 0
 //   1. walks the descriptors back from the range start until a closed tile to

@@ -53,6 +53,27 @@ def main():
         tot += med if "only" not in k else 0.0
         print(f"{k:28s} median {med*1e3:9.1f} us  min {mn*1e3:9.1f} us   {m/med/1e6:8.2f} Gpairs/s")
     print(f"bin+fwd+bwd {tot*1e3:.1f} us -> {m/tot/1e6:.2f} Gpairs/s end to end (whole Function)")
+    # the same three steps with a caller-bounded entry count (no device->host read), eagerly and as ONE replayed HIP graph
+    cap = int(1.25 * bins.n_tile_pairs) + 4096
+
+    def whole(capacity):
+        b = raster.bin_tiles(sc["start"], sc["end"], w, h, capacity=capacity)
+        im, c = raster.blend_forward(b, *args_, with_checkpoints=True)
+        return raster.blend_backward(b, *args_, c, gimg)
+
+    t_sync = timeit(lambda: whole(None))
+    t_cap = timeit(lambda: whole(cap))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        whole(cap)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        outs = whole(cap)
+    t_graph = timeit(graph.replay)
+    print(f"bin+fwd+bwd in one go: exact K (one read-back) {t_sync[0]*1e3:.1f} us | capacity {cap} (no read-back) {t_cap[0]*1e3:.1f} us | "
+          f"the same as one replayed HIP graph {t_graph[0]*1e3:.1f} us")
     # a batch of cameras (the reference renders them one after the other, gs_model.py:402-449): 1 vs 2 streams
     cams = [sc] * 6
     for ns in (() if args.no_cameras else (1, 2, 3)):

@@ -461,6 +461,22 @@ def main():
 
     # ---- outside the timed region ------------------------------------------------------------------------------
     walked = gc.last_lookback_tiles(dev)
+    # the pair the reference's live path actually calls: grouped_cumprod_forward, and
+    # grouped_cumsum_forward on flipped arrays = one reverse scan here (gs_model.py:716-722); 12 + 12 B/pair
+    er = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    gc.grouped_cumsum_reverse(p.grad_out, p.key, gin)
+    er[0].record()
+    for _ in range(10):
+        gc.grouped_cumsum_reverse(p.grad_out, p.key, gin)
+    er[1].record()
+    torch.cuda.synchronize()
+    t_rev = er[0].elapsed_time(er[1]) / 10 * 1e-3
+    live_pair = {
+        "what": "grouped_cumprod_forward + suffix-sum scan (the reference's flip / grouped_cumsum_forward / flip), 24 B/pair",
+        "reverse_scan_us": t_rev * 1e6,
+        "pairs_per_s": m / (t_fwd + t_rev),
+        "frac_of_hbm_peak": 24 * m / (t_fwd + t_rev) / 1e9 / HBM_PEAK_GBPS,
+    }
 
     def scan_fwd_bwd(q):
         yy = scan_fwd_bwd.buf.setdefault(("y", q.n_pairs), torch.empty_like(q.x))
@@ -551,6 +567,7 @@ def main():
                 "tiles_resolved_through_the_descriptor_tree": walked,
                 "world_size_checked": world,
                 "unclipped": unclipped,
+                "live_path_pair": live_pair,
             },
             "sharded_frames": sharded,
             "roofline": {

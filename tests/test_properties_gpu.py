@@ -75,6 +75,44 @@ def test_scan_properties_random_structures(device, lens, seed):
     _check_properties(gc, x, z, key)
 
 
+# group lengths that reach over many tiles and over the descriptor tree's 64-tile blocks (64 x 4096 = 262 144 elements)
+_long = st.one_of(st.integers(1, 30), st.integers(4000, 4200), st.integers(260_000, 264_500), st.integers(1, 1_300_000))
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(lens=st.lists(_long, min_size=1, max_size=8), carry_in=st.booleans())
+def test_descriptor_tree_random_structures_exact(device, lens, carry_in):
+    """Random mixes of tiny, tile-sized, block-sized and multi-block groups: integer-valued sums are exact in fp32 under
+    any association, so forward / reverse / backward-of-ones / carry variants must reproduce positions bit for bit."""
+    import grouped_cumprod as gc
+
+    lens_t = torch.tensor(lens, dtype=torch.long, device=device)
+    n = int(lens_t.sum())
+    ids = torch.arange(len(lens), device=device, dtype=torch.int32)
+    inv = torch.repeat_interleave(ids, lens_t)
+    starts = torch.cumsum(lens_t, 0) - lens_t
+    ends = torch.cumsum(lens_t, 0)
+    idx = torch.arange(n, device=device)
+    pos = (idx - starts[inv.long()] + 1).float()
+    rem = (ends[inv.long()] - idx).float()
+    ones = torch.ones(n, device=device)
+    out = torch.empty(n, device=device)
+    if carry_in:
+        carry = (ids.float() * 3.0 + 5.0).contiguous()           # small integers: sums stay exact below 2^24
+        gc.grouped_cumsum_forward_carry(ones, inv, carry, out)
+        assert torch.equal(out, pos + carry[inv.long()])
+        gc.grouped_cumsum_reverse_carry(ones, inv, carry, out)
+        assert torch.equal(out, rem + carry[inv.long()])
+    else:
+        gc.grouped_cumsum_forward(ones, inv, out)
+        assert torch.equal(out, pos)
+        gc.grouped_cumsum_reverse(ones, inv, out)
+        assert torch.equal(out, rem)
+        gc.grouped_cumprod_backward(ones, ones, ones, inv, out, torch.zeros(1, dtype=torch.int32, device=device))
+        assert torch.equal(out, rem)
+    assert gc.last_fallback_tiles(device) == 0
+
+
 def test_scan_properties_full_size_cfg3(device):
     """The same properties on BASELINE.json's metric configuration (M ~ 1.66e8 pairs)."""
     import grouped_cumprod as gc

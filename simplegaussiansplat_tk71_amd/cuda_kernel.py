@@ -70,15 +70,26 @@ def tile_capacity(n_entries):
         _capacity = old
 
 
+def _note_capacity_flag(flag):
+    """Remember a device-side overflow flag without reading it; many pending flags of one device are folded into one on
+    the device so that a caller who never asks does not accumulate tensors."""
+    global _pending_info
+    _pending_info.append(flag)
+    if len(_pending_info) >= 64:
+        by_dev = {}
+        for f in _pending_info:
+            by_dev.setdefault(f.device, []).append(f)
+        _pending_info = [torch.stack(fs).max() for fs in by_dev.values()]
+
+
 def capacity_exceeded():
     """True if any Function call since the last check ran out of its `tile_capacity` (those calls dropped the Gaussians
     that did not fit: rerun the step with a larger bound).  One device->host read for all pending calls."""
     global _pending_info
     if not _pending_info:
         return False
-    flags = torch.stack([i[1] for i in _pending_info])
-    _pending_info = []
-    return bool(flags.any().item())
+    flags, _pending_info = _pending_info, []
+    return any(bool(f.item()) for f in ([torch.stack([g for g in flags if g.device == d]).max() for d in {g.device for g in flags}]))
 
 
 
@@ -246,7 +257,7 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
             w, h = int(image_width), int(image_height)
             bins = _raster.bin_tiles(startpoint, endpoint, w, h, capacity=_capacity)
             if bins.info is not None:
-                _pending_info.append(bins.info)
+                _note_capacity_flag(bins.info[1])
             image, t_ckpt = _raster.blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d,
                                                   with_checkpoints=True)
         ctx.bins = bins

@@ -362,6 +362,28 @@ def test_hip_graph_capture_and_replay(device):
     assert_parity(g, co.cumprod_backward_f64(x2, want_y, go.cpu(), inv).float(), scale, "graph replay backward")
 
 
+@pytest.mark.parametrize("ntiles", [2, 3, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097])
+@pytest.mark.parametrize("tail", [0, 1, 4095])
+def test_descriptor_tree_block_boundaries_exact(device, ntiles, tail):
+    """Tile counts on both sides of the radix-64 tree's block sizes (64, 4096 tiles), arrays that end on a tile boundary,
+    one element past it and one short of the next: two groups that split the array in the middle (each below 2^24
+    elements, so sums of ones are exact), forward and reverse."""
+    import grouped_cumprod as gc
+
+    n = (ntiles - 1) * gc.tile_elems() + (tail if tail else gc.tile_elems())
+    half = n // 2 + 17
+    key = torch.zeros(n, dtype=torch.int32, device=device)
+    key[half:] = 7
+    idx = torch.arange(n, device=device)
+    ones = torch.ones(n, device=device)
+    out = torch.empty(n, device=device)
+    gc.grouped_cumsum_forward(ones, key, out)
+    assert torch.equal(out, torch.where(idx < half, idx + 1, idx - half + 1).float())
+    gc.grouped_cumsum_reverse(ones, key, out)
+    assert torch.equal(out, torch.where(idx < half, half - idx, n - idx).float())
+    assert gc.last_fallback_tiles(device) == 0
+
+
 def test_descriptor_tree_levels_exact_integers(device):
     """Groups of 3e5 .. 9e5 elements and one of 1.6e7 over 4 915 tiles: every tile's carry comes from the radix-64
     descriptor tree, across level-1 (64 tiles) and level-2 (4 096 tiles) block boundaries.  Sums of ones are exact

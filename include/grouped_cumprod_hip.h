@@ -299,7 +299,9 @@ int gcp_pixel_lists_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t
  * keep uint8 (the cull mask of gs_model.py:405-407) and row_of = -1.
  * gcp_project_gather: for the first n_kept entries of the sorted permutation `perm`, the Function's arguments in
  * depth order (boxes, pixel means, boxsize = gs_model.py:425, Sigma'^-1 [4], opacity, l_d [3], index = Gaussian id)
- * and row_of[index[r]] = r.
+ * and row_of[index[r]] = r.  With `keep` (the mask gcp_project_forward wrote) and n_kept = n_gauss, the list holds ALL
+ * Gaussians without the kept count ever being read back: the culled ones follow the kept ones with an empty box (binned
+ * into no tile, blended nowhere, zero gradients) — the capture-safe form; keep = NULL: the first n_kept entries only.
  * gcp_project_backward: gradients of (mean, quaternion, log scale, opacity logit, SH coefficients), n_gauss rows
  * each, all rows written (zeros where row_of < 0), from those of (Sigma'^-1, opacity, l_d) in list order. */
 int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
@@ -308,7 +310,7 @@ int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* 
                         uint8_t* keep, int32_t* row_of, void* stream);
 int gcp_project_gather(const float* record, const int32_t* perm, int64_t n_kept, int32_t* start_xy, int32_t* end_xy,
                        int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha, float* l_d, int64_t* index,
-                       int32_t* row_of, void* stream);
+                       int32_t* row_of, const uint8_t* keep /* may be NULL */, void* stream);
 int gcp_project_backward(const float* mean, const float* quat_xyzw, const float* log_scale, const float* opacity_logit,
                          const float* sh_coeff, const float* cam_P, const float* cam_K, int64_t n_gauss, int32_t sh_degree,
                          int32_t n_basis, const int32_t* row_of, const float* grad_vinv, const float* grad_alpha,

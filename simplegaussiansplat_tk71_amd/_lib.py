@@ -74,7 +74,7 @@ SIGNATURES = {
     "gcp_pixel_lists_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5),
     "gcp_pixel_lists_fill": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 8),
     "gcp_project_forward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32, _i32, _i32, ctypes.c_float] + [_c_void_p] * 5),
-    "gcp_project_gather": (ctypes.c_int, [_c_void_p, _c_void_p, _i64] + [_c_void_p] * 10),
+    "gcp_project_gather": (ctypes.c_int, [_c_void_p, _c_void_p, _i64] + [_c_void_p] * 11),
     "gcp_adam_step": (ctypes.c_int, [_c_void_p] * 4 + [_i64] + [ctypes.c_double] * 4 + [_i64, _c_void_p]),
     "gcp_ssim_blocks": (_i64, [_i64, _i32, _i32]),
     "gcp_ssim_l1_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, ctypes.c_float, ctypes.c_float]

@@ -243,12 +243,17 @@ __global__ __launch_bounds__(kThreads) void k_project_fwd(
 __global__ __launch_bounds__(kThreads) void k_project_gather(
     const float4* __restrict__ record, const int* __restrict__ perm, i64 m, int* __restrict__ start_xy,
     int* __restrict__ end_xy, int* __restrict__ mean_xy, i64* __restrict__ boxsize, float* __restrict__ vinv,
-    float* __restrict__ alpha, float* __restrict__ l_d, i64* __restrict__ index, int* __restrict__ row_of) {
+    float* __restrict__ alpha, float* __restrict__ l_d, i64* __restrict__ index, int* __restrict__ row_of,
+    const unsigned char* __restrict__ keep) {
   for (i64 r = (i64)blockIdx.x * kThreads + threadIdx.x; r < m; r += (i64)gridDim.x * kThreads) {
     const int i = perm[r];
     const float4* rec = record + 4 * (i64)i;
     const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
-    const int x0 = __float_as_int(a.x), y0 = __float_as_int(a.y), x1 = __float_as_int(a.z), y1 = __float_as_int(a.w);
+    int x0 = __float_as_int(a.x), y0 = __float_as_int(a.y), x1 = __float_as_int(a.z), y1 = __float_as_int(a.w);
+    // `keep` given (the list holds ALL Gaussians, no kept count was read back): a culled one stays in the list behind
+    // the kept ones with an EMPTY box — binned into no tile, blended nowhere, zero gradients (its row_of stays -1)
+    const bool culled = keep != nullptr && keep[i] == 0;
+    if (culled) { x0 = 1; y0 = 1; x1 = 0; y1 = 0; }
     reinterpret_cast<int2*>(start_xy)[r] = make_int2(x0, y0);
     reinterpret_cast<int2*>(end_xy)[r] = make_int2(x1, y1);
     reinterpret_cast<int2*>(mean_xy)[r] = make_int2(__float_as_int(b.x), __float_as_int(b.y));
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_project_gather(
     alpha[r] = c.z;
     l_d[3 * r] = c.w, l_d[3 * r + 1] = d.x, l_d[3 * r + 2] = d.y;
     index[r] = i;
-    row_of[i] = (int)r;
+    if (!culled) row_of[i] = (int)r;
   }
 }
 
@@ -472,14 +477,15 @@ int gcp_project_forward(const float* mean, const float* quat_xyzw, const float* 
 
 int gcp_project_gather(const float* record, const int32_t* perm, int64_t n_kept, int32_t* start_xy, int32_t* end_xy,
                        int32_t* mean_xy, int64_t* boxsize, float* vinv, float* alpha, float* l_d, int64_t* index,
-                       int32_t* row_of, void* stream) {
+                       int32_t* row_of, const uint8_t* keep, void* stream) {
   if (n_kept < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n_kept == 0) return GCP_OK;
   if (!record || !perm || !start_xy || !end_xy || !mean_xy || !boxsize || !vinv || !alpha || !l_d || !index || !row_of ||
       (((uintptr_t)record | (uintptr_t)vinv) & 15) || (((uintptr_t)start_xy | (uintptr_t)end_xy | (uintptr_t)mean_xy) & 7))
     return GCP_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_project_gather, dim3(grid_for(n_kept)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)record, perm,
-                     (i64)n_kept, start_xy, end_xy, mean_xy, (i64*)boxsize, vinv, alpha, l_d, (i64*)index, row_of);
+                     (i64)n_kept, start_xy, end_xy, mean_xy, (i64*)boxsize, vinv, alpha, l_d, (i64*)index, row_of,
+                     (const unsigned char*)keep);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

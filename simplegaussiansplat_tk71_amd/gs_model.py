@@ -96,7 +96,8 @@ class _ProjectCamera(torch.autograd.Function):
     stable radix sort on the depth keys, gcp_project_gather; backward = gcp_project_backward."""
 
     @staticmethod
-    def forward(ctx, mean, variance_q, variance_scale, opacity, color, cam_P, cam_K, width, height, box_clamp, L_max):
+    def forward(ctx, mean, variance_q, variance_scale, opacity, color, cam_P, cam_K, width, height, box_clamp, L_max,
+                capture_safe=False):
         dev, n = mean.device, mean.shape[0]
         args = [t.detach().contiguous() for t in (mean, variance_q, variance_scale, opacity, color, cam_P, cam_K)]
         for t in args:
@@ -114,7 +115,9 @@ class _ProjectCamera(torch.autograd.Function):
             _lib.check(lib.gcp_project_forward(*(t.data_ptr() for t in args), n, L_max, color.shape[1], width, height, box_clamp,
                                                record.data_ptr(), sort_key.data_ptr(), keep.data_ptr(), row_of.data_ptr(), stream),
                        "gcp_project_forward")
-            m = int(keep.sum()) if n else 0  # the one device->host read: sizes of the outputs
+            # the one device->host read: sizes of the outputs.  capture_safe: none — the list keeps all n Gaussians, the
+            # culled ones behind the kept ones with empty boxes (gcp_project_gather with the keep mask)
+            m = n if capture_safe else (int(keep.sum()) if n else 0)
             # culled Gaussians carry the largest key: the first m entries of the stable permutation are the kept ones in
             # depth order, ties in the Gaussians' own order
             perm = _raster.stable_sort_keys(sort_key, key_bits=31)[1] if n else sort_key
@@ -122,7 +125,8 @@ class _ProjectCamera(torch.autograd.Function):
             vinv, alpha, l_d, index = f32(m, 2, 2), f32(m, 1), f32(m, 3), torch.empty(m, dtype=torch.int64, device=dev)
             _lib.check(lib.gcp_project_gather(record.data_ptr(), perm.data_ptr(), m, start.data_ptr(), end.data_ptr(),
                                               mean_xy.data_ptr(), boxsize.data_ptr(), vinv.data_ptr(), alpha.data_ptr(),
-                                              l_d.data_ptr(), index.data_ptr(), row_of.data_ptr(), stream), "gcp_project_gather")
+                                              l_d.data_ptr(), index.data_ptr(), row_of.data_ptr(),
+                                              keep.data_ptr() if capture_safe else None, stream), "gcp_project_gather")
         keep = keep.view(torch.bool)
         ctx.save_for_backward(*args, row_of)
         ctx.L_max = L_max
@@ -141,10 +145,10 @@ class _ProjectCamera(torch.autograd.Function):
             _lib.check(_lib.load().gcp_project_backward(
                 *(t.data_ptr() for t in args), mean.shape[0], ctx.L_max, color.shape[1], row_of.data_ptr(),
                 *(t.data_ptr() for t in g), *(t.data_ptr() for t in grads), stream), "gcp_project_backward")
-        return (*grads, None, None, None, None, None, None)
+        return (*grads, None, None, None, None, None, None, None)
 
 
-def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max=2):
+def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, tile_max_width, L_max=2, capture_safe=False):
     """Per camera, the depth-ordered, culled arguments of the Function (reference: gs_model.py:277-425).
 
     mean (N,3), variance_q (N,4 xyzw), variance_scale (N,3 log), opacity (N,1 logit), color (N,(L+1)^2,3),
@@ -154,14 +158,19 @@ def camera_inputs(mean, variance_q, variance_scale, opacity, color, P, K, wh, ti
     and the (N,) bool `grad_iter` of Gaussians seen by any camera (:401-407).
 
     One HIP kernel per camera and direction (csrc/gcp_project.hip); GPU tensors only — there is no CPU path.  The
-    reference's op-by-op PyTorch formulation lives in oracle/gs_forward_torch.py as the checker."""
-    width, height = (int(v) for v in wh[0].tolist())  # the one device->host read of the image size (.to(int32) truncates, :279)
+    reference's op-by-op PyTorch formulation lives in oracle/gs_forward_torch.py as the checker.
+
+    capture_safe=True: no device->host read at all (pass `wh` as a CPU tensor or a list): every camera's list keeps all N
+    Gaussians in depth order, the culled ones behind the kept ones with EMPTY boxes (binned into no tile, zero
+    gradients), and no camera is ever dropped; images and gradients are those of the default mode.  Together with
+    `cuda_kernel.tile_capacity` the projection + Function forward and backward queue without waiting for the GPU."""
+    width, height = (int(v) for v in (wh[0].tolist() if isinstance(wh, torch.Tensor) else wh[0]))  # device `wh`: one read (.to(int32) truncates, :279)
     clamp = _box_clamp(width, height, tile_max_width)
     grad_iter = None
     cams = []
     for c in range(P.shape[0]):
         vinv, alpha, l_d, start, end, mean_xy, boxsize, index, keep = _ProjectCamera.apply(
-            mean, variance_q, variance_scale, opacity, color, P[c], K[c], width, height, clamp, L_max)
+            mean, variance_q, variance_scale, opacity, color, P[c], K[c], width, height, clamp, L_max, capture_safe)
         grad_iter = keep if grad_iter is None else grad_iter | keep
         cams.append(None if index.numel() == 0 else {
             "boxsize": boxsize, "startpoint": start, "endpoint": end, "mean": mean_xy, "variance_inverse": vinv,

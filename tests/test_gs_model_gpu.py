@@ -156,6 +156,64 @@ def test_fused_projection_equals_torch_formulation(n, n_cam, width, height, sh_d
         assert float(gradf["color"][:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
 
 
+def test_capture_safe_projection_and_function_equal_the_default_and_run_as_one_graph(device):
+    """camera_inputs(capture_safe=True) reads nothing back: every camera's list keeps all N Gaussians, the culled ones
+    with empty boxes behind the kept ones.  Image and all five parameter gradients equal the default mode's bit for
+    bit, and projection + Function forward + backward are captured into ONE HIP graph and replayed on moved Gaussians."""
+    import cuda_kernel as ck
+
+    n, width, height = 4000, 96, 64
+    w = random_world(n, 2, width, height, 11, device)
+    names = ("mean", "variance_q", "variance_scale", "opacity", "color")
+    wh_host = [[width, height]] * 2
+    target = torch.rand(2, height + 1, width + 1, 3, device=device)
+
+    def run(leaves, capture_safe):
+        cams, grad_iter, (wd, ht) = gm.camera_inputs(*(leaves[k] for k in names), w["P"], w["K"], wh_host if capture_safe else w["wh"],
+                                                     TILE_LOGIT, capture_safe=capture_safe)
+        imgs = []
+        for cam in cams:
+            imgs.append(ck.custom_autograd_grouped_cumprod.apply(cam["boxsize"], None, cam["startpoint"], cam["endpoint"], cam["mean"],
+                                                                 cam["variance_inverse"], cam["opacity"], cam["l_d"], wd - 1, ht - 1))
+        img = torch.stack(imgs)
+        grads = torch.autograd.grad(((img - target[:, : img.shape[1], : img.shape[2]]) ** 2).sum(), [leaves[k] for k in names])
+        return img, grads, grad_iter, cams
+
+    leaves = {k: w[k].clone().requires_grad_(True) for k in names}
+    img0, g0, it0, cams0 = run(leaves, False)
+    with ck.tile_capacity(8 * n):
+        img1, g1, it1, cams1 = run(leaves, True)
+    assert not ck.capacity_exceeded()
+    assert all(c["index"].numel() == n for c in cams1) and all(c["index"].numel() < n for c in cams0)  # something was culled
+    assert torch.equal(it0, it1) and torch.equal(img0, img1)
+    for a, b, k in zip(g0, g1, names):
+        assert torch.equal(a, b), k
+    # (outputs of earlier eager runs that are still referenced — live autograd nodes of the custom Functions — make
+    # torch's capture_end crash on this stack, with or without this library's capture-safe mode: drop them first)
+    del img0, g0, it0, cams0, img1, g1, it1, cams1
+    # one graph: projection, binning, blend forward, blend backward, projection backward
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with ck.tile_capacity(8 * n), torch.cuda.stream(side):
+        warm = run(leaves, True)
+        del warm
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with ck.tile_capacity(8 * n), torch.cuda.graph(graph, stream=side):
+        outs = run(leaves, True)
+    with torch.no_grad():
+        leaves["mean"].add_(0.05 * torch.randn_like(leaves["mean"]))
+        leaves["opacity"].sub_(0.3)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert not ck.capacity_exceeded()
+    got_img, got_grads = outs[0].clone(), [g.clone() for g in outs[1]]
+    img2, g2, _, _ = run(leaves, False)   # the default (synchronising) mode on the moved Gaussians
+    assert torch.equal(got_img, img2)
+    for a, b, k in zip(got_grads, g2, names):
+        assert torch.equal(a, b), k
+
+
 def test_fused_projection_argument_checks(device):
     w = random_world(50, 1, 32, 24, 3, device)
     args = [w[k] for k in ("mean", "variance_q", "variance_scale", "opacity", "color")]

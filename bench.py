@@ -353,7 +353,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg3", help="cfg2 | cfg3 | cfg5band (one 8th of the 4K frame)")
+    ap.add_argument("--workload", default="cfg3",
+                    help="cfg2 | cfg3 | cfg5band (one 8th of the 4K frame) | cfg3_unclipped (cfg3's run-length mix without the "
+                         "clip at 4096 splats per pixel: a few pixels deeper than one scan tile)")
     ap.add_argument("--cpu-sample", type=int, default=64_000_000, help="pairs in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -401,14 +403,18 @@ def main():
             print(f"[bench] process group up: backend {backend}, world size {dist.get_world_size()}", file=sys.stderr, flush=True)
 
     # this rank's band of the frame; bands are independent pair lists (no exchange on the scan path)
+    unclipped_headline = args.workload.endswith("_unclipped")
+    if unclipped_headline:
+        args.workload = args.workload[: -len("_unclipped")]
     if args.workload == "cfg5band":
         rows = synthetic.CONFIGS["cfg5"]["height"] // 8
         p = synthetic.make_config("cfg5", seed=rank, device=dev, rows=rows, row_start=rank * rows)
         wl = f"cfg5 band: 3840x{rows} rows of the 3840x2160 / 5M-Gaussian frame, mean 100 splats/pixel (deep)"
     else:
         c = synthetic.CONFIGS[args.workload]
-        p = synthetic.make_config(args.workload, seed=rank, device=dev, row_start=rank * c["height"])
-        wl = (
+        p = synthetic.make_config(args.workload, seed=rank, device=dev, row_start=rank * c["height"],
+                                  **({"max_run": None} if unclipped_headline else {}))
+        wl = ("" if not unclipped_headline else "UNCLIPPED (no limit of 4096 splats per pixel) ") + (
             f"{args.workload}: {c['width']}x{c['height']}, {c['gaussians']} Gaussians, mean {c['mean_depth']:g} "
             f"splats/pixel ({'deep heavy-tailed lists' if c['deep'] else 'Poisson'})"
         )

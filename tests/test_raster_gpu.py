@@ -399,6 +399,31 @@ def test_gaussians_behind_an_opaque_stack_get_accurate_gradients(device):
         assert float(rel.max()) < 1e-3, (name, float(rel.max()), int(rel.argmax()))
 
 
+def _full_cover_scales(sc, n):
+    """Scenes whose boxes all cover the whole image: the per-(Gaussian, pixel) terms have a closed dense form (fp64), and
+    with them the CONDITION SCALE of every gradient — the sum over pixels of the |terms| whose signed sum it is — so a
+    bound can be stated relative to the Gaussian's own terms instead of the scene's largest gradient.
+    Returns (scales per gradient name, exclusive transmittance T[n, P])."""
+    w, h = sc["width"], sc["height"]
+    ys, xs = torch.meshgrid(torch.arange(h + 1, dtype=torch.float64), torch.arange(w + 1, dtype=torch.float64), indexing="ij")
+    dx = xs.reshape(1, -1) - sc["mean"][:, 0:1].double()
+    dy = ys.reshape(1, -1) - sc["mean"][:, 1:2].double()
+    v = sc["vinv"].double()
+    gk = torch.exp(-0.5 * (dx * dx * v[:, 0, 0, None] + dx * dy * (v[:, 0, 1, None] + v[:, 1, 0, None]) + dy * dy * v[:, 1, 1, None]))
+    a = sc["opacity"].double() * gk                                                   # [n, P]
+    T = torch.cumprod(torch.cat([torch.ones(1, a.size(1), dtype=torch.float64), 1.0 - a[:-1]]), 0)   # exclusive
+    c = sc["l_d"].double() @ sc["wimg"].double().reshape(-1, 3).T                      # dL/dI . l   [n, P]
+    S = torch.flip(torch.cumsum(torch.flip(T * a * c, [0]), 0), [0]) - T * a * c       # exclusive suffix sums
+    sa = S / (1.0 - a)
+    abs_o = (T * gk * c.abs() + gk * sa.abs()).sum(1)                                  # scale of dL/do (gs_model.py:733-740)
+    abs_c = T * a * c.abs() + a * sa.abs()                                             # scale of the "common" factor
+    abs_l = (T * a)[:, :, None] * sc["wimg"].double().reshape(1, -1, 3).abs()          # [n, P, 3]
+    scales = {"opacity": abs_o[:, None], "l_d": abs_l.sum(1),
+              "vinv": 0.5 * torch.stack([(abs_c * dx * dx).sum(1), (abs_c * (dx * dy).abs()).sum(1), (abs_c * (dx * dy).abs()).sum(1),
+                                         (abs_c * dy * dy).sum(1)], 1)}
+    return scales, T
+
+
 def _stack_scene(n_layers, opacity_lo, opacity_hi, seed, w=15, h=15):
     """`n_layers` wide Gaussians over one 16x16 tile: every pixel's list is n_layers deep."""
     g = torch.Generator().manual_seed(seed)
@@ -429,26 +454,8 @@ def test_deep_pixel_columns_relative_gradient_accuracy(device, n_layers, op_lo, 
     i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"],
                                                  sc["width"], sc["height"], sc["wimg"])
     torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
-    # Every box covers the whole image, so the per-(Gaussian, pixel) terms have a closed dense form (fp64): with them
-    # the CONDITION SCALE of every gradient — the sum over pixels of the |terms| whose signed sum it is — is known, and
-    # the bound can be stated relative to the Gaussian's own terms instead of the scene's largest gradient.
-    n, w, h = n_layers, sc["width"], sc["height"]
-    ys, xs = torch.meshgrid(torch.arange(h + 1, dtype=torch.float64), torch.arange(w + 1, dtype=torch.float64), indexing="ij")
-    dx = xs.reshape(1, -1) - sc["mean"][:, 0:1].double()
-    dy = ys.reshape(1, -1) - sc["mean"][:, 1:2].double()
-    v = sc["vinv"].double()
-    gk = torch.exp(-0.5 * (dx * dx * v[:, 0, 0, None] + dx * dy * (v[:, 0, 1, None] + v[:, 1, 0, None]) + dy * dy * v[:, 1, 1, None]))
-    a = sc["opacity"].double() * gk                                                   # [n, P]
-    T = torch.cumprod(torch.cat([torch.ones(1, a.size(1), dtype=torch.float64), 1.0 - a[:-1]]), 0)   # exclusive
-    c = sc["l_d"].double() @ sc["wimg"].double().reshape(-1, 3).T                      # dL/dI . l   [n, P]
-    S = torch.flip(torch.cumsum(torch.flip(T * a * c, [0]), 0), [0]) - T * a * c       # exclusive suffix sums
-    sa = S / (1.0 - a)
-    abs_o = (T * gk * c.abs() + gk * sa.abs()).sum(1)                                  # scale of dL/do (gs_model.py:733-740)
-    abs_c = T * a * c.abs() + a * sa.abs()                                             # scale of the "common" factor
-    abs_l = (T * a)[:, :, None] * sc["wimg"].double().reshape(1, -1, 3).abs()          # [n, P, 3]
-    scales = {"opacity": abs_o[:, None], "l_d": abs_l.sum(1),
-              "vinv": 0.5 * torch.stack([(abs_c * dx * dx).sum(1), (abs_c * (dx * dy).abs()).sum(1), (abs_c * (dx * dy).abs()).sum(1),
-                                         (abs_c * dy * dy).sum(1)], 1)}
+    n = n_layers
+    scales, T = _full_cover_scales(sc, n)
     assert float((T[:, 120] < 1e-2).double().mean()) > 0.3 and float(T[-1, 120]) < 1e-3    # the list really runs into occlusion
     seen = {}
     for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
@@ -459,6 +466,31 @@ def test_deep_pixel_columns_relative_gradient_accuracy(device, n_layers, op_lo, 
         seen[name] = (float(scale.max()), float(scale.min()), float((err / (scale + 1e-300)).max()))
     print(f"{n_layers} layers, opacity [{op_lo}, {op_hi}], T at the list end {float(T[-1, 120]):.1e}: per-Gaussian (largest "
           f"condition scale, smallest, max err / scale): {seen}")
+
+
+@pytest.mark.parametrize("name", ["deep_300", "deep_700"])
+def test_deep_stacks_vs_the_reference_functions_own_outputs(device, name):
+    """tests/golden/function_deep_golden.npz = the reference's own custom_autograd_grouped_cumprod (its reverse scan
+    `grad_cumsum`, gs_model.py:716-722) run on CPU on 300- and 700-layer pixel lists whose transmittance falls to 1e-9 /
+    1e-20 (generator: tests/golden/make_function_deep_golden.py).  The HIP Function's image and its opacity / covariance
+    gradients must agree with the REFERENCE's — each Gaussian within 4e-5 of its own condition scale (the reference is
+    fp32 itself) — over the 18 orders of magnitude those gradients span."""
+    z = np.load(os.path.join(GOLD, "function_deep_golden.npz"))
+    g = lambda k: torch.from_numpy(z[f"{name}/{k}"])  # noqa: E731
+    w, h = (int(v) for v in z[name + "/width_height"])
+    sc = dict(boxsize=g("boxsize"), start=g("start"), end=g("end"), mean=g("mean"), vinv=g("vinv"), opacity=g("opacity"),
+              l_d=g("l_d"), wimg=g("wimg"), width=w, height=h)
+    n = sc["start"].size(0)
+    img, gv, go, gl = _apply(device, sc)
+    torch.testing.assert_close(img, g("image"), atol=TOL, rtol=TOL)
+    scales, T = _full_cover_scales(sc, n)
+    assert float(T[-1].median()) < (1e-7 if name == "deep_300" else 1e-15)  # the lists really run deep into occlusion
+    for what, got, want in (("opacity", go, g("grad_opacity")), ("vinv", gv, g("grad_vinv"))):
+        got, want = got.double().reshape(n, -1), want.double().reshape(n, -1)
+        err = (got - want).abs()
+        bound = 4e-5 * scales[what] + 1e-30
+        assert bool((err <= bound).all()), (what, float((err / (scales[what] + 1e-300)).max()), int((err > bound).any(1).nonzero()[0]))
+    assert float(g("grad_opacity").abs().min()) < 1e-8 < 1.0 < float(g("grad_opacity").abs().max())  # the span is real
 
 
 def test_random_small_scenes_against_the_dense_oracle(device):

@@ -186,6 +186,30 @@ def test_dense_renderer_vs_reference_function_golden(name):
     assert not torch.allclose(gl.float(), g("grad_l_REFERENCE_BUGGY"), atol=1e-3, rtol=1e-2)
 
 
+@pytest.mark.parametrize("name", ["deep_300", "deep_700"])
+def test_dense_renderer_vs_reference_function_deep_golden(name):
+    """The dense fp64 oracle against the reference's own Function at DEPTH (300 / 700 layers per pixel, gradients from
+    1e-18 to 19; tests/golden/function_deep_golden.npz): image, and every Gaussian's opacity / precision-matrix gradient
+    within 2e-5 of its own condition scale (tests/util.full_cover_scales: the sum over pixels of the |terms| whose signed sum
+    it is; the reference is fp32) — the oracle the HIP backward is held to is itself pinned to the reference where the old
+    total-minus-prefix backward went wrong."""
+    from oracle import dense_render as dr
+    from tests.util import full_cover_scales
+
+    z = np.load(os.path.join(GOLD, "function_deep_golden.npz"))
+    g = lambda k: torch.from_numpy(z[f"{name}/{k}"])  # noqa: E731
+    w, h = (int(v) for v in z[name + "/width_height"])
+    img, gv, go, gl = dr.render_with_grads(g("start"), g("end"), g("mean"), g("vinv"), g("opacity"), g("l_d"), w, h, g("wimg"))
+    torch.testing.assert_close(img.float(), g("image"), atol=1e-5, rtol=1e-5)
+    n = go.shape[0]
+    sc = dict(mean=g("mean"), vinv=g("vinv"), opacity=g("opacity"), l_d=g("l_d"), wimg=g("wimg"), width=w, height=h)
+    scales, _ = full_cover_scales(sc, n)
+    for what, got, want in (("opacity", go, g("grad_opacity")), ("vinv", gv, g("grad_vinv"))):
+        got, want = got.reshape(n, -1), want.double().reshape(n, -1)
+        assert bool(((got - want).abs() <= 2e-5 * scales[what] + 1e-30).all()), what
+    assert float(g("grad_opacity").abs().min()) < 1e-8
+
+
 def test_reference_backward_breaks_when_a_suffix_sum_is_exactly_zero():
     """SURVEY §0 Q9 (found while building the goldens): `grad_cumsum` returns its mask in FLIPPED order
     (gs_model.py:720-722) and `_backward_batch` applies it to un-flipped tensors (:642-645).  Harmless while the

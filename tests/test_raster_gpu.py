@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import TOL, make_scene
+from tests.util import TOL, full_cover_scales, make_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -399,31 +399,6 @@ def test_gaussians_behind_an_opaque_stack_get_accurate_gradients(device):
         assert float(rel.max()) < 1e-3, (name, float(rel.max()), int(rel.argmax()))
 
 
-def _full_cover_scales(sc, n):
-    """Scenes whose boxes all cover the whole image: the per-(Gaussian, pixel) terms have a closed dense form (fp64), and
-    with them the CONDITION SCALE of every gradient — the sum over pixels of the |terms| whose signed sum it is — so a
-    bound can be stated relative to the Gaussian's own terms instead of the scene's largest gradient.
-    Returns (scales per gradient name, exclusive transmittance T[n, P])."""
-    w, h = sc["width"], sc["height"]
-    ys, xs = torch.meshgrid(torch.arange(h + 1, dtype=torch.float64), torch.arange(w + 1, dtype=torch.float64), indexing="ij")
-    dx = xs.reshape(1, -1) - sc["mean"][:, 0:1].double()
-    dy = ys.reshape(1, -1) - sc["mean"][:, 1:2].double()
-    v = sc["vinv"].double()
-    gk = torch.exp(-0.5 * (dx * dx * v[:, 0, 0, None] + dx * dy * (v[:, 0, 1, None] + v[:, 1, 0, None]) + dy * dy * v[:, 1, 1, None]))
-    a = sc["opacity"].double() * gk                                                   # [n, P]
-    T = torch.cumprod(torch.cat([torch.ones(1, a.size(1), dtype=torch.float64), 1.0 - a[:-1]]), 0)   # exclusive
-    c = sc["l_d"].double() @ sc["wimg"].double().reshape(-1, 3).T                      # dL/dI . l   [n, P]
-    S = torch.flip(torch.cumsum(torch.flip(T * a * c, [0]), 0), [0]) - T * a * c       # exclusive suffix sums
-    sa = S / (1.0 - a)
-    abs_o = (T * gk * c.abs() + gk * sa.abs()).sum(1)                                  # scale of dL/do (gs_model.py:733-740)
-    abs_c = T * a * c.abs() + a * sa.abs()                                             # scale of the "common" factor
-    abs_l = (T * a)[:, :, None] * sc["wimg"].double().reshape(1, -1, 3).abs()          # [n, P, 3]
-    scales = {"opacity": abs_o[:, None], "l_d": abs_l.sum(1),
-              "vinv": 0.5 * torch.stack([(abs_c * dx * dx).sum(1), (abs_c * (dx * dy).abs()).sum(1), (abs_c * (dx * dy).abs()).sum(1),
-                                         (abs_c * dy * dy).sum(1)], 1)}
-    return scales, T
-
-
 def _stack_scene(n_layers, opacity_lo, opacity_hi, seed, w=15, h=15):
     """`n_layers` wide Gaussians over one 16x16 tile: every pixel's list is n_layers deep."""
     g = torch.Generator().manual_seed(seed)
@@ -455,7 +430,7 @@ def test_deep_pixel_columns_relative_gradient_accuracy(device, n_layers, op_lo, 
                                                  sc["width"], sc["height"], sc["wimg"])
     torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
     n = n_layers
-    scales, T = _full_cover_scales(sc, n)
+    scales, T = full_cover_scales(sc, n)
     assert float((T[:, 120] < 1e-2).double().mean()) > 0.3 and float(T[-1, 120]) < 1e-3    # the list really runs into occlusion
     seen = {}
     for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
@@ -483,7 +458,7 @@ def test_deep_stacks_vs_the_reference_functions_own_outputs(device, name):
     n = sc["start"].size(0)
     img, gv, go, gl = _apply(device, sc)
     torch.testing.assert_close(img, g("image"), atol=TOL, rtol=TOL)
-    scales, T = _full_cover_scales(sc, n)
+    scales, T = full_cover_scales(sc, n)
     assert float(T[-1].median()) < (1e-7 if name == "deep_300" else 1e-15)  # the lists really run deep into occlusion
     for what, got, want in (("opacity", go, g("grad_opacity")), ("vinv", gv, g("grad_vinv"))):
         got, want = got.double().reshape(n, -1), want.double().reshape(n, -1)

@@ -99,3 +99,28 @@ def make_scene(n_gauss, width, height, max_half, seed, opacity_one_every=0):
     wimg = torch.randn(height + 1, width + 1, 3, generator=g)
     return dict(boxsize=boxsize, start=start, end=end, mean=mean, vinv=vinv, opacity=opacity, l_d=l_d, wimg=wimg,
                 width=width, height=height)
+
+
+def full_cover_scales(sc, n):
+    """Scenes whose boxes all cover the whole image: the per-(Gaussian, pixel) terms have a closed dense form (fp64), and
+    with them the CONDITION SCALE of every gradient — the sum over pixels of the |terms| whose signed sum it is — so a
+    bound can be stated relative to the Gaussian's own terms instead of the scene's largest gradient.
+    Returns (scales per gradient name, exclusive transmittance T[n, P])."""
+    w, h = sc["width"], sc["height"]
+    ys, xs = torch.meshgrid(torch.arange(h + 1, dtype=torch.float64), torch.arange(w + 1, dtype=torch.float64), indexing="ij")
+    dx = xs.reshape(1, -1) - sc["mean"][:, 0:1].double()
+    dy = ys.reshape(1, -1) - sc["mean"][:, 1:2].double()
+    v = sc["vinv"].double()
+    gk = torch.exp(-0.5 * (dx * dx * v[:, 0, 0, None] + dx * dy * (v[:, 0, 1, None] + v[:, 1, 0, None]) + dy * dy * v[:, 1, 1, None]))
+    a = sc["opacity"].double() * gk                                                   # [n, P]
+    T = torch.cumprod(torch.cat([torch.ones(1, a.size(1), dtype=torch.float64), 1.0 - a[:-1]]), 0)   # exclusive
+    c = sc["l_d"].double() @ sc["wimg"].double().reshape(-1, 3).T                      # dL/dI . l   [n, P]
+    S = torch.flip(torch.cumsum(torch.flip(T * a * c, [0]), 0), [0]) - T * a * c       # exclusive suffix sums
+    sa = S / (1.0 - a)
+    abs_o = (T * gk * c.abs() + gk * sa.abs()).sum(1)                                  # scale of dL/do (gs_model.py:733-740)
+    abs_c = T * a * c.abs() + a * sa.abs()                                             # scale of the "common" factor
+    abs_l = (T * a)[:, :, None] * sc["wimg"].double().reshape(1, -1, 3).abs()          # [n, P, 3]
+    scales = {"opacity": abs_o[:, None], "l_d": abs_l.sum(1),
+              "vinv": 0.5 * torch.stack([(abs_c * dx * dx).sum(1), (abs_c * (dx * dy).abs()).sum(1), (abs_c * (dx * dy).abs()).sum(1),
+                                         (abs_c * dy * dy).sum(1)], 1)}
+    return scales, T

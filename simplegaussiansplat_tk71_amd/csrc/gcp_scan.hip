@@ -546,6 +546,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   int zl = 0;
   while (zl < kLevels - 1 && ((lt >> (6 * zl)) & 63) == 63) ++zl;
   auto entry = [&](int level, i64 idx) -> unsigned long long* { return desc + 2 * (a.lvl_off[level] + idx); };
+  const int lvl = lane < kLevels ? lane : kLevels - 1;  // lane -> level for the lanes that publish upper levels (in bounds for all)
   const bool need_carry = s_wf[kWaves] != 0;
   if (a.ntiles > 1 && (need_carry || (!has_head && zl > 0))) {  // block-uniform, rare
     if (w == 0) {
@@ -556,7 +557,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       if (lane == 0)
         __hip_atomic_store(entry(0, lt), pack_desc(agg, has_head ? 0u : kDOpen, first_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (has_head && lane >= 1 && lane <= zl)
-        __hip_atomic_store(entry(lane, lt >> (6 * lane)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(entry(lvl, lt >> (6 * lvl)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // lane i at level L looks at block (t >> 6L) - 1 - i of that level, for i < digit L of t: the blocks between the
       // start of the enclosing level-(L+1) block and this tile, nearest first
       int pub_level = has_head ? zl : 0;  // levels 1 .. pub_level are published
@@ -639,7 +640,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       if (lane == 0)
         __hip_atomic_store(entry(0, lt), pack_desc(agg, fl, first_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (has_head && !need_carry && lane >= 1 && lane <= zl)
-        __hip_atomic_store(entry(lane, lt >> (6 * lane)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(entry(lvl, lt >> (6 * lvl)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #pragma unroll

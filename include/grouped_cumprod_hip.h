@@ -27,11 +27,13 @@
  *   - launches are asynchronous on `stream`; no host synchronisation, no
  *     allocation when a workspace is supplied (graph-capturable);
  *   - every function returns GCP_OK (0) or a GCP_ERR_* code; n == 0 is a no-op;
- *   - results are deterministic run to run (no value-carrying atomics).
+ *   - results are deterministic run to run, bit for bit, whatever the timing: no value-carrying atomic, and a tile
+ *     that is finished by the follow-up launch (below) gets the bits it would have got inside the main launch.
  *
  * Workspace: the scans are single-pass.  A group longer than one tile's raw look-back window (4096 elements)
  * continues on per-tile descriptors inside the same launch; a tile that would have to wait too long for another
- * tile's descriptor is finished by a small follow-up launch (a no-op otherwise).  Both need
+ * tile's descriptor is finished by a small follow-up launch (a no-op otherwise), which completes the descriptor
+ * tree in the main launch's fixed association and re-runs the tile with the carry taken from it.  Both need
  * gcp_workspace_bytes(n) bytes of scratch (0.4 % of one array).  Pass ws == NULL to let the library use an internal
  * per-device scratch buffer (grown with hipMalloc on demand — not graph-capturable, and not safe for concurrent
  * launches on two streams).  A caller-provided workspace must be zeroed ONCE before its first use
@@ -160,7 +162,8 @@ int gcp_last_fallback_tiles(void* ws, void* stream, int64_t* n_tiles);
 /* Longest time (microseconds) a tile waits for another tile's descriptor before it leaves its carry to the
  * follow-up launch; default 200 (environment GCP_DESC_WAIT_US).  0 = look once, never wait; negative = skip the
  * descriptor walk altogether (every group that starts more than one tile back goes to the follow-up launch — the
- * two-pass behaviour, kept for tests and A/B timing).  Process-wide; results are identical for every setting. */
+ * two-pass behaviour, kept for tests and A/B timing).  Process-wide; results are bit-identical for every setting
+ * (tests/test_scan_gpu.py::test_results_do_not_depend_on_the_descriptor_wait). */
 int gcp_set_lookback_wait_us(int64_t us);
 /* Number of tiles of that scan whose group started more than one tile back and that resolved their carry through
  * the descriptor look-back inside the main launch. */

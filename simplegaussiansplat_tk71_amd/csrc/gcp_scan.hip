@@ -96,6 +96,8 @@ constexpr int kHdrTiles = 3;        // [3], [4]: tiles written in descriptor set
 constexpr int kHdrDescResolved = 5; // tiles that took their carry from the block tree in the last launch (introspection;
                                     // counted by the follow-up kernel from a flag in the level-0 descriptors: one atomic per
                                     // tile inside the main kernel serialises at the L2 and cost 1 ms per 40 000 tiles)
+constexpr int kHdrAnyUnresolved = 6; // set (plain store) by any tile that gave up waiting; read and cleared by the follow-up kernel
+constexpr int kHdrBarrier = 7;      // arrival counter of the follow-up kernel's grid barriers (rare path only)
 // descriptor = {aggregate bits (low word), flags (high word)}
 constexpr unsigned kDOpen = 1u;        // the aggregate is relative to the tile's (still unknown) carry-in: no head in the tile
 constexpr unsigned kDUnresolved = 2u;  // the tile's leading elements still lack their carry (the fallback kernel's work list)
@@ -270,9 +272,11 @@ __device__ __forceinline__ unsigned long long pack_desc(float agg, unsigned flag
 // ----------------------------------------------------------------------------
 // Main kernel: one tile per block.
 // ----------------------------------------------------------------------------
-template <int MODE, bool ALIGNED, bool FULL, bool CARRY>
+// FIXUP: the follow-up kernel re-runs a tile whose wait for the descriptor tree ran out, with the carry `fix_carry` it
+// took from the (completed) tree: same code, same association, so the tile gets the bits it would have got in time.
+template <int MODE, bool ALIGNED, bool FULL, bool CARRY, bool FIXUP = false>
 __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float* s_wv, int* s_wf,
-                                          float* s_tc, int* s_fh) {
+                                          float* s_tc, int* s_fh, const float fix_carry = 0.0f) {
   typedef Mode<MODE> MD;
   constexpr bool REV = MD::kRev;
   constexpr bool BWD = MD::kBwd;
@@ -341,7 +345,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   if (nb_exists) nbk = a.key[pn];
 
   // look-back chunk 0 (wave 0 only): issued now so its latency overlaps
-  const bool do_lb = (w == 0) && (lt > 0);
+  const bool do_lb = !FIXUP && (w == 0) && (lt > 0);
   float4_t lbv = {id, id, id, id};
   int4_t lbk = {0, 0, 0, 0};
   i64 lbp = 0;
@@ -446,7 +450,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   // reaches further back, chunks are fetched kLbBatch at a time (one dependent
   // round trip per batch) up to one full tile.
   if (w == 0) {
-    float tc = id;
+    float tc = FIXUP ? fix_carry : id;
     int unresolved = 0;
     if (do_lb) {
       const int k0 = __builtin_amdgcn_readfirstlane(kk[0].x);
@@ -548,7 +552,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   auto entry = [&](int level, i64 idx) -> unsigned long long* { return desc + 2 * (a.lvl_off[level] + idx); };
   const int lvl = lane < kLevels ? lane : kLevels - 1;  // lane -> level for the lanes that publish upper levels (in bounds for all)
   const bool need_carry = s_wf[kWaves] != 0;
-  if (a.ntiles > 1 && (need_carry || (!has_head && zl > 0))) {  // block-uniform, rare
+  if (!FIXUP && a.ntiles > 1 && (need_carry || (!has_head && zl > 0))) {  // block-uniform, rare
     if (w == 0) {
       int first_head;
       float agg;
@@ -611,8 +615,9 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         }
       }
       if (lane == 0 && need_carry) {
-        s_tc[0] = resolved ? tc : id;  // unresolved: outputs stay relative, the follow-up kernel folds the prefix in
+        s_tc[0] = resolved ? tc : id;  // unresolved: the follow-up kernel re-runs this tile with the carry from the completed tree
         s_wf[kWaves + 1] = resolved ? 0 : 1;
+        if (!resolved) a.hdr[kHdrAnyUnresolved] = 1u;
       }
     }
     __syncthreads();
@@ -626,7 +631,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     if (j < w) R = s_wf[j] ? s_wv[j] : M::op(R, s_wv[j]);
   // ---- level-0 descriptor in its final form (and, for a tile with a head, all its levels), before the stores:
   //      the tiles behind may be waiting for it ----
-  if (w == kWaves - 1) {
+  if (!FIXUP && w == kWaves - 1) {
     if (lt == 0 && lane == 0) {  // per-launch bookkeeping
       a.hdr[kHdrUnresolved] = 0;
       a.hdr[kHdrDescResolved] = 0;
@@ -688,190 +693,178 @@ void gcp_scan_main(const ScanArgs a) {
 }
 
 // ----------------------------------------------------------------------------
-// Follow-up ("fallback") kernel, one small launch after every multi-tile scan: finishes the
-// tiles whose wait for the descriptor tree ran out (none in practice; all long-group tiles in
-// two-pass mode) and maintains the workspace.  Block b owns the
-// contiguous tile range [b*per, (b+1)*per).  Common case: no tile of the range
-// is unresolved -> one coalesced descriptor read and return.  Otherwise wave 0
-//   1. walks the descriptors back from the range start until a closed tile to
-//      get the prefix entering the range (64 descriptors per step),
-//   2. runs a segmented scan over the range, 64 tiles per step, which yields
-//      the prefix entering every tile,
-// and all 4 waves fold that prefix into elements [0, first_head) of every
-// unresolved tile.  Cost is O(ntiles/64) steps per block even for one group
-// spanning the whole array.
+// Follow-up ("fallback") kernel, one small launch after every multi-tile scan.  It maintains the
+// workspace (counts the introspection flags, clears the descriptor set the next launch will publish
+// into, advances the launch counter) and — only when some tile of the main kernel gave up waiting for
+// the descriptor tree (kHdrAnyUnresolved; every long-group tile in two-pass mode) — finishes those
+// tiles with THE SAME BITS the tree would have given them in time:
+//   1. the upper tree levels are completed bottom-up (one wave per missing entry, the association of the
+//      main kernel's publisher; a grid barrier between levels — the grid is at most kFixBlocks blocks,
+//      all resident),
+//   2. wave 0 of the block that owns an unresolved tile takes the tile's carry from the tree with the
+//      search of the main kernel (nothing to wait for any more),
+//   3. the block re-runs scan_tile<FIXUP> on the tile with that carry.
+// Every value involved is a fixed-association function of the level-0 descriptors and the raw inputs,
+// so a launch with time-outs is bit-identical to one without (tests/test_scan_gpu.py::
+// test_results_do_not_depend_on_the_descriptor_wait).
 // ----------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ float fix_one(float out, float cin, float x) {
-  typedef Mode<MODE> MD;
-  if (MD::kBwd) return out + cin / (x != 0.0f ? x : 1e-8f);
-  return Monoid<MD::kMul>::op(cin, out);
+__device__ __forceinline__ unsigned long long ld_entry(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the up-to-`count` entries idx-1, idx-2, ... of one level, nearest first (lane i = entry idx-1-i), reduced up to and
+// including the nearest one that holds a head: exactly the lanes, mask and DPP tree of the main kernel's walk
+template <bool MUL>
+__device__ __forceinline__ float reduce_nearest(const unsigned long long* level, i64 idx, int count, int lane, bool& closed) {
+  typedef Monoid<MUL> M;
+  unsigned long long d = 0ull;
+  if (lane < count) d = ld_entry(level + 2 * (idx - 1 - lane));
+  const unsigned fl = (unsigned)(d >> 32);
+  const float val = __builtin_bit_cast(float, (unsigned)d);
+  const unsigned long long am = count ? ((count >= 64) ? ~0ull : ((1ull << count) - 1ull)) : 0ull;
+  const unsigned long long cm = __ballot(lane < count && (fl & kDOpen) == 0u);
+  const int lf = cm ? __builtin_ctzll(cm) : 63;
+  const unsigned long long want = am & ((lf >= 63) ? ~0ull : ((2ull << lf) - 1ull));
+  closed = cm != 0ull;
+  return wave_reduce<MUL>(((want >> lane) & 1ull) ? val : M::identity());
+}
+
+// entry `idx` of level L >= 1 from its 64 children at level L - 1 (what the last tile of the block publishes in the main kernel)
+template <bool MUL>
+__device__ __forceinline__ unsigned long long rebuild_entry(const unsigned long long* desc, const i64* lvl_off, int L, i64 idx, int lane) {
+  typedef Monoid<MUL> M;
+  const unsigned long long* level = desc + 2 * lvl_off[L - 1];
+  const i64 lastc = (idx << 6) + 63;
+  const unsigned long long last = ld_entry(level + 2 * lastc);
+  const float lval = __builtin_bit_cast(float, (unsigned)last);
+  if ((((unsigned)(last >> 32)) & kDOpen) == 0u) return pack_desc(lval, 0u, 0);  // the last child holds a head: its trailing aggregate
+  bool closed;
+  const float part = reduce_nearest<MUL>(level, lastc, 63, lane, closed);
+  return pack_desc(M::op(part, lval), closed ? 0u : kDOpen, 0);
+}
+
+// the prefix entering tile lt, from the completed tree: level by level, nearest blocks first (main kernel, "the carry")
+template <bool MUL>
+__device__ __forceinline__ float tree_carry(const unsigned long long* desc, const i64* lvl_off, i64 lt, int lane) {
+  typedef Monoid<MUL> M;
+  float acc = M::identity();
+  for (int L = 0; L < kLevels; ++L) {
+    const i64 self = lt >> (6 * L);
+    bool closed;
+    const float part = reduce_nearest<MUL>(desc + 2 * lvl_off[L], self, (int)(self & 63), lane, closed);
+    acc = M::op(part, acc);  // older blocks on the left
+    if (closed || (lt >> (6 * (L + 1))) == 0) break;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
 }
 
 // Every block, whatever it finds, also (i) clears its share of the OTHER descriptor set over the range its last user
 // wrote — the set the next launch on this workspace will publish into — and (ii) counts itself done; the last block
 // to finish advances the launch counter, which flips the sets.  Nobody reads the other set or the counter's parity
 // after that point in this launch, so neither needs a barrier.
-template <int MODE>
-__device__ __forceinline__ void fallback_body(const ScanArgs& a, const uint2* desc);
-
-template <int MODE>
+template <int MODE, bool CARRY>
 __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
+  typedef Mode<MODE> MD;
+  __shared__ float s_wv[kWaves];
+  __shared__ int s_wf[kWaves + 2];
+  __shared__ float s_tc[1];
+  __shared__ int s_fh[kWaves];
+  __shared__ int s_any, s_tree, s_cnt;
+  __shared__ int s_tile[64];
+  __shared__ float s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned epoch = a.hdr[kHdrEpoch];
   const unsigned set = epoch & 1u;
-  fallback_body<MODE>(a, reinterpret_cast<const uint2*>(a.desc_sets + set));
-  unsigned long long* const other = a.desc_sets + (set ^ 1u);
-  const i64 n_other = (i64)a.hdr[kHdrTiles + (set ^ 1u)];
-  const i64 per = (n_other + gridDim.x - 1) / gridDim.x;
-  const i64 z0 = (i64)blockIdx.x * per;
-  const i64 z1 = (z0 + per < n_other) ? (z0 + per) : n_other;
-  for (i64 t = z0 + threadIdx.x; t < z1; t += kThreads) other[2 * t] = 0ull;
-  __syncthreads();  // every thread's clears are issued before the block reports itself done
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(a.hdr + kHdrDone, 1u) == gridDim.x - 1) {
-      a.hdr[kHdrDone] = 0;
-      a.hdr[kHdrEpoch] = epoch + 1u;
-    }
-  }
-}
-
-template <int MODE>
-__device__ __forceinline__ void fallback_body(const ScanArgs& a, const uint2* desc) {
-  typedef Mode<MODE> MD;
-  constexpr bool REV = MD::kRev;
-  typedef Monoid<MD::kMul> M;
-  const float id = M::identity();
-  __shared__ int s_any;
-  __shared__ int s_cnt;
-  __shared__ int s_tile[64];
-  __shared__ float s_carry[64];
-  __shared__ int s_first[64];
-  __shared__ float s_wv[kWaves];
-  __shared__ int s_wf[kWaves];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const i64 n = a.n;
+  unsigned long long* const desc = a.desc_sets + set;
+  const bool any = a.hdr[kHdrAnyUnresolved] != 0u;  // the same for every block: written by the main kernel only
   const i64 per = (a.ntiles + gridDim.x - 1) / gridDim.x;
   const i64 r0 = (i64)blockIdx.x * per;
   const i64 r1 = (r0 + per < a.ntiles) ? (r0 + per) : a.ntiles;
-  if (r0 >= r1) return;
 
-  __shared__ int s_tree;
+  // introspection counters of this launch, from the flags of the level-0 descriptors
   if (tid == 0) { s_any = 0; s_tree = 0; }
   __syncthreads();
-  int mine = 0, tree = 0;
-  for (i64 t = r0 + tid; t < r1; t += kThreads) {
-    const unsigned fl = desc[2 * t].y;
-    mine += (int)((fl >> 1) & 1u);
-    tree += (int)((fl >> 16) & 1u);
+  {
+    int mine = 0, tree = 0;
+    for (i64 t = r0 + tid; t < r1; t += kThreads) {
+      const unsigned fl = (unsigned)(desc[2 * t] >> 32);
+      mine += (int)((fl >> 1) & 1u);
+      tree += (int)((fl >> 16) & 1u);
+    }
+    if (mine) atomicAdd(&s_any, mine);
+    if (tree) atomicAdd(&s_tree, tree);
   }
-  if (mine) atomicAdd(&s_any, mine);
-  if (tree) atomicAdd(&s_tree, tree);
   __syncthreads();
-  const int n_unres = s_any;
   if (tid == 0 && s_tree) atomicAdd(a.hdr + kHdrDescResolved, (unsigned)s_tree);
-  if (n_unres == 0) return;
-  if (tid == 0) atomicAdd(a.hdr + kHdrUnresolved, (unsigned)n_unres);
+  if (tid == 0 && s_any) atomicAdd(a.hdr + kHdrUnresolved, (unsigned)s_any);
 
-  // 1. prefix entering tile r0 = inclusive aggregate of tile r0-1: walk back 256 descriptors per
-  //    step (wave w takes distances 64w+1 .. 64w+64) until a closed tile; every thread ends with C.
-  float C = id;
-  for (i64 t = r0; t > 0; t -= kThreads) {
-    const i64 idx = t - 1 - tid;  // tid 0 = nearest predecessor
-    uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 0u);  // before the array: closed, identity
-    if (idx >= 0) d = desc[2 * idx];
-    const bool closed = (d.y & 1u) == 0u;
-    const unsigned long long cm = __ballot(closed);
-    const int lc = cm ? __builtin_ctzll(cm) : 64;
-    const float contrib = (lane <= lc) ? __builtin_bit_cast(float, d.x) : id;
-    const float part = wave_reduce<MD::kMul>(contrib);
-    if (lane == 0) { s_wv[w] = part; s_wf[w] = (lc < 64) ? 1 : 0; }
-    __syncthreads();
-    bool found = false;
-#pragma unroll
-    for (int j = 0; j < kWaves; ++j) {
-      if (!found) { C = M::op(s_wv[j], C); found = s_wf[j] != 0; }
+  if (any) {  // grid-uniform
+    // 1. complete the upper levels, bottom-up
+    unsigned phase = 0;
+    for (int L = 1; L < kLevels; ++L) {
+      const i64 n_complete = a.ntiles >> (6 * L);  // blocks of 64^L tiles that lie wholly inside the array
+      if (n_complete == 0) break;
+      unsigned long long* const level = desc + 2 * a.lvl_off[L];
+      for (i64 idx = (i64)blockIdx.x * kWaves + w; idx < n_complete; idx += (i64)gridDim.x * kWaves) {
+        if ((((unsigned)(ld_entry(level + 2 * idx) >> 32)) & kDValid) != 0u) continue;  // published in time (wave-uniform)
+        const unsigned long long e = rebuild_entry<MD::kMul>(desc, a.lvl_off, L, idx, lane);
+        if (lane == 0) __hip_atomic_store(level + 2 * idx, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      grid_barrier(a.hdr + kHdrBarrier, ++phase * gridDim.x);
     }
-    __syncthreads();
-    if (found) break;  // uniform: every thread read the same LDS words
+    // 2. + 3. this block's unresolved tiles
+    if (s_any) {  // block-uniform
+      for (i64 c0 = r0; c0 < r1; c0 += 64) {
+        if (w == 0) {
+          const i64 t = c0 + lane;
+          const bool unres = t < r1 && ((((unsigned)(ld_entry(desc + 2 * t) >> 32)) & kDUnresolved) != 0u);
+          const unsigned long long um = __ballot(unres);
+          if (unres) s_tile[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = lane;
+          if (lane == 0) s_cnt = __builtin_popcountll(um);
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int i = 0; i < cnt; ++i) {
+          const i64 lt = c0 + s_tile[i];
+          if (w == 0) {
+            const float c = tree_carry<MD::kMul>(desc, a.lvl_off, lt, lane);
+            if (lane == 0) s_carry = c;
+          }
+          __syncthreads();
+          const float c = s_carry;
+          // guarded dword form of the tile routine: the same arithmetic as the vector form on any alignment and tile
+          scan_tile<MODE, false, false, CARRY, true>(a, lt, s_wv, s_wf, s_tc, s_fh, c);
+          __syncthreads();
+        }
+        __syncthreads();
+      }
+    }
   }
 
-  // 2. range scan, 64 tiles per step (wave 0), then all threads fold the prefix into the
-  //    physical interval [lo, hi) that holds elements [0, first_head) of every unresolved tile
-  for (i64 c0 = r0; c0 < r1; c0 += 64) {
-    if (w == 0) {
-      const i64 t = c0 + lane;
-      uint2 d = make_uint2(__builtin_bit_cast(unsigned, id), 1u);  // past the range: open, identity, resolved
-      if (t < r1) d = desc[2 * t];
-      const bool closed = (d.y & 1u) == 0u;
-      const bool unres = ((d.y >> 1) & 1u) != 0u;
-      const unsigned long long cm = __ballot(closed);
-      const unsigned long long upto = cm & (~0ull >> (63 - lane));
-      const int h = upto ? (63 - __clzll(upto)) : -1;
-      const float inc = wave_seg_scan<MD::kMul>(__builtin_bit_cast(float, d.x), h, lane);
-      const float ex = dpp_f<0x138, 0xf>(id, inc);
-      const bool open_before = (cm & ((1ull << lane) - 1ull)) == 0ull;
-      const float cin = open_before ? M::op(C, ex) : ex;  // prefix entering tile t
-      const unsigned long long um = __ballot(unres);
-      if (unres) {
-        const int slot = __builtin_popcountll(um & ((1ull << lane) - 1ull));
-        s_tile[slot] = (int)(t - c0);
-        s_carry[slot] = cin;
-        s_first[slot] = (int)((d.y >> 2) & 0x1fffu);
-      }
-      if (lane == 0) s_cnt = __builtin_popcountll(um);
-      const float tot = readlane_f(inc, 63);
-      C = cm ? tot : M::op(C, tot);
+  unsigned long long* const other = a.desc_sets + (set ^ 1u);
+  const i64 n_other = (i64)a.hdr[kHdrTiles + (set ^ 1u)];
+  const i64 oper = (n_other + gridDim.x - 1) / gridDim.x;
+  const i64 z0 = (i64)blockIdx.x * oper;
+  const i64 z1 = (z0 + oper < n_other) ? (z0 + oper) : n_other;
+  for (i64 t = z0 + tid; t < z1; t += kThreads) other[2 * t] = 0ull;
+  __syncthreads();  // every thread's clears are issued before the block reports itself done
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(a.hdr + kHdrDone, 1u) == gridDim.x - 1) {
+      a.hdr[kHdrDone] = 0;
+      a.hdr[kHdrAnyUnresolved] = 0;
+      a.hdr[kHdrBarrier] = 0;
+      a.hdr[kHdrEpoch] = epoch + 1u;
     }
-    __syncthreads();
-    const int cnt = s_cnt;
-    for (int i = 0; i < cnt; ++i) {
-      const i64 lt = c0 + s_tile[i];
-      const float cin = s_carry[i];
-      const int first = s_first[i];
-      const i64 pt = REV ? (a.ntiles - 1 - lt) : lt;
-      const i64 base = pt * (i64)kTile;
-      i64 lo = REV ? (base + kTile - first) : base;
-      i64 hi = REV ? (base + kTile) : (base + first);
-      if (hi > n) hi = n;
-      if (lo < 0) lo = 0;
-      const bool vec = ((((uintptr_t)a.out | (uintptr_t)a.in0) & 15u) == 0);
-      // vector body over 16-byte aligned groups fully inside [lo, hi): 4 groups in flight per thread
-      const i64 vlo = vec ? ((lo + 3) & ~(i64)3) : hi;
-      const i64 vhi = vec ? (hi & ~(i64)3) : hi;
-      const i64 head_end = vlo < hi ? vlo : hi;
-      for (i64 p = lo + tid; p < head_end; p += kThreads)
-        a.out[p] = fix_one<MODE>(a.out[p], cin, MD::kBwd ? a.in0[p] : 0.0f);
-      if (vlo < vhi) {
-        const i64 ngrp = (vhi - vlo) >> 2;
-        for (i64 g0 = tid; g0 < ngrp; g0 += 4 * kThreads) {
-          float4_t o[4], x[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const i64 g = g0 + (i64)u * kThreads;
-            if (g < ngrp) {
-              o[u] = *reinterpret_cast<const float4_t*>(a.out + vlo + 4 * g);
-              if (MD::kBwd) x[u] = *reinterpret_cast<const float4_t*>(a.in0 + vlo + 4 * g);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const i64 g = g0 + (i64)u * kThreads;
-            if (g < ngrp) {
-              float4_t r;
-              r.x = fix_one<MODE>(o[u].x, cin, MD::kBwd ? x[u].x : 0.0f);
-              r.y = fix_one<MODE>(o[u].y, cin, MD::kBwd ? x[u].y : 0.0f);
-              r.z = fix_one<MODE>(o[u].z, cin, MD::kBwd ? x[u].z : 0.0f);
-              r.w = fix_one<MODE>(o[u].w, cin, MD::kBwd ? x[u].w : 0.0f);
-              *reinterpret_cast<float4_t*>(a.out + vlo + 4 * g) = r;
-            }
-          }
-        }
-      }
-      for (i64 p = ((vlo < vhi) ? vhi : head_end) + tid; p < hi; p += kThreads)
-        a.out[p] = fix_one<MODE>(a.out[p], cin, MD::kBwd ? a.in0[p] : 0.0f);
-    }
-    __syncthreads();
   }
 }
 
@@ -1013,7 +1006,8 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
     // grid is small unless the descriptor walk is switched off and the kernel has real work on every long group
     const i64 want = a.patience < 0 ? kFixBlocks : kFixBlocksQuiet;
     const unsigned fb = (unsigned)(ntiles < want ? ntiles : want);
-    hipLaunchKernelGGL((gcp_fallback<MODE>), dim3(fb), dim3(kThreads), 0, stream, a);
+    if (carry) hipLaunchKernelGGL((gcp_fallback<MODE, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
+    else hipLaunchKernelGGL((gcp_fallback<MODE, false>), dim3(fb), dim3(kThreads), 0, stream, a);
     GCP_HIP(hipGetLastError());
   }
   return GCP_OK;

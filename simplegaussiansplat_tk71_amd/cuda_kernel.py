@@ -46,23 +46,38 @@ __all__ = [
     "custom_autograd_grouped_cumprod",
     "tile_capacity",
     "capacity_exceeded",
+    "GraphedStep",
 ]
 
 # Capture-safe mode of the Function (no device->host read inside forward / backward): the caller bounds the number of
-# (tile, Gaussian) entries of a camera; whether a bound was too small is read back once per step, after the fact.
+# (tile, Gaussian) entries of a camera; whether a bound was too small is OR-ed into one sticky int32 per device that
+# lives outside every graph's memory pool (so a replayed graph keeps reporting) and is read back once per step.
 _capacity = None
-_pending_info = []
+_sticky = {}  # device index -> int32[1], never freed: captured graphs hold its address
+
+
+def _sticky_flag(device):
+    flag = _sticky.get(device.index)
+    if flag is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("tile_capacity: enter the context BEFORE the capture begins (the overflow flag of "
+                               f"{device} must not be allocated inside a graph's private pool)")
+        flag = _sticky[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return flag
 
 
 @contextlib.contextmanager
-def tile_capacity(n_entries):
+def tile_capacity(n_entries, device=None):
     """Inside this context `custom_autograd_grouped_cumprod.apply` bins with a caller-given bound on the (tile, Gaussian)
     entry count (about 3 per Gaussian at BASELINE's box sizes; a Gaussian covers ceil(w/16+1) x ceil(h/16+1) tiles at
     most) instead of reading the exact count back from the device — the reference synchronises on `.item()` per chunk
     (gs_model.py:677,793,801-802).  Forward and backward then queue their kernels without ever waiting for the GPU and
-    can be captured into a HIP graph.  Pass image_width / image_height as Python ints or CPU tensors (a device tensor
-    would have to be read back).  Call `capacity_exceeded()` once per step."""
+    can be captured into a HIP graph (`GraphedStep`).  Pass image_width / image_height as Python ints or CPU tensors (a
+    device tensor would have to be read back).  Call `capacity_exceeded()` once per step — also after every replay of a
+    captured step: the flag is written by the captured kernels themselves."""
     global _capacity
+    if torch.cuda.is_available():
+        _sticky_flag(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
     old, _capacity = _capacity, int(n_entries)
     try:
         yield
@@ -70,27 +85,68 @@ def tile_capacity(n_entries):
         _capacity = old
 
 
-def _note_capacity_flag(flag):
-    """Remember a device-side overflow flag without reading it; many pending flags of one device are folded into one on
-    the device so that a caller who never asks does not accumulate tensors."""
-    global _pending_info
-    _pending_info.append(flag)
-    if len(_pending_info) >= 64:
-        by_dev = {}
-        for f in _pending_info:
-            by_dev.setdefault(f.device, []).append(f)
-        _pending_info = [torch.stack(fs).max() for fs in by_dev.values()]
-
-
 def capacity_exceeded():
-    """True if any Function call since the last check ran out of its `tile_capacity` (those calls dropped the Gaussians
-    that did not fit: rerun the step with a larger bound).  One device->host read for all pending calls."""
-    global _pending_info
-    if not _pending_info:
-        return False
-    flags, _pending_info = _pending_info, []
-    return any(bool(f.item()) for f in ([torch.stack([g for g in flags if g.device == d]).max() for d in {g.device for g in flags}]))
+    """True if any Function call — eager, or replayed from a graph — since the last check ran out of its
+    `tile_capacity` (those calls dropped the Gaussians that did not fit, from the back of the depth order, with zero
+    gradients: rerun the step with a larger bound).  One device->host read per device in use; resets the flags."""
+    hit = False
+    for flag in _sticky.values():
+        with torch.cuda.device(flag.device):
+            if bool(flag.item()):
+                hit = True
+                flag.zero_()
+    return hit
 
+
+class GraphedStep:
+    """One training-step body — `fn(*params)` -> loss, or a tuple whose first entry is the loss — with its backward,
+    captured into ONE HIP graph and replayed with `replay()` -> (outputs of fn, gradients w.r.t. params).
+
+    The step is traced through fresh ALIASES of the parameters (`p.detach().requires_grad_()`: same storage, so
+    in-place updates of `p` are seen by every replay; new autograd leaves).  Why: a leaf's AccumulateGrad node is
+    created lazily under the stream that is current when the leaf first enters an autograd graph, and stays alive as
+    long as any such graph does (the previous step's loss, logged outputs, ...).  After eager steps on the default
+    stream a backward captured on a side stream hands its gradients to that old node; the engine then makes the
+    node's stream — the legacy default stream — wait on an event recorded inside the capture, which pulls the default
+    stream into it, and `capture_end` of this ROCm stack segfaults (tools/capture_repro.py reproduces it with three
+    lines of plain PyTorch; torch only warns "AccumulateGrad node's stream does not match").  Aliases created on the
+    capture stream have no history, so whatever the caller still holds cannot reach the capture.
+
+    `capacity`: bound for `tile_capacity` around every trace of `fn` (None: `fn` must not contain a host read).  After
+    `replay()` call `capacity_exceeded()` as after an eager step."""
+
+    def __init__(self, fn, params, capacity=None, warmup=2, stream=None):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("GraphedStep: no parameters")
+        dev = self.params[0].device
+        self._fn = fn
+        self._capacity = capacity
+        self.stream = torch.cuda.Stream(device=dev) if stream is None else stream
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, int(warmup))):  # allocator warm-up and lazy initialisations outside the capture
+                self._trace()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        self.graph = torch.cuda.CUDAGraph()
+        with self._bound(), torch.cuda.graph(self.graph, stream=self.stream):
+            self.outputs, self.grads = self._trace(bounded=False)
+
+    def _bound(self):
+        return tile_capacity(self._capacity, self.params[0].device) if self._capacity is not None else contextlib.nullcontext()
+
+    def _trace(self, bounded=True):
+        with (self._bound() if bounded else contextlib.nullcontext()):
+            leaves = [p.detach().requires_grad_(True) for p in self.params]
+            out = self._fn(*leaves)
+            loss = out[0] if isinstance(out, (tuple, list)) else out
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        outs = tuple(o.detach() if isinstance(o, torch.Tensor) else o for o in out) if isinstance(out, (tuple, list)) else out.detach()
+        return outs, grads
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs, self.grads
 
 
 class GroupedCumprod(torch.autograd.Function):
@@ -256,22 +312,27 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
         with torch.no_grad():
             w, h = int(image_width), int(image_height)
             bins = _raster.bin_tiles(startpoint, endpoint, w, h, capacity=_capacity)
-            if bins.info is not None:
-                _note_capacity_flag(bins.info[1])
+            if bins.info is not None:  # sticky: survives the call, and is re-executed by every replay of a captured step
+                flag = _sticky_flag(bins.info.device)
+                torch.maximum(flag, bins.info[1:2], out=flag)
             image, t_ckpt = _raster.blend_forward(bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d,
                                                   with_checkpoints=True)
-        ctx.bins = bins
         # the reference saves its inputs plus per-chunk (unique_rects, T_min, sizes) and recomputes the M-length pair
-        # arrays in backward (gs_model.py:691, :786-820); here: the inputs plus one transmittance per pixel and 32 list entries
-        ctx.save_for_backward(startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt)
+        # arrays in backward (gs_model.py:691, :786-820); here: the inputs, one transmittance per pixel and 32 list
+        # entries, and the tile lists.  Every tensor goes through save_for_backward (autograd then owns its lifetime and
+        # checks it for in-place changes); the node itself keeps only integers.
+        ctx.bins_meta = (bins.width, bins.height, bins.n_gauss, bins.n_tile_pairs, bins.tiles_x, bins.tiles_y)
+        ctx.save_for_backward(startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, bins.tile_off,
+                              bins.tile_start, bins.tile_list)
         return image
 
     @staticmethod
     def backward(ctx, pixel_sum_grad):
-        startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt = ctx.saved_tensors
+        startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, tile_off, tile_start, tile_list = ctx.saved_tensors
+        bins = _raster.TileBins(*ctx.bins_meta, tile_off, tile_start, tile_list)
         with torch.no_grad():
             g_mean, g_vinv, g_op, g_l = _raster.blend_backward(
-                ctx.bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, pixel_sum_grad
+                bins, startpoint, endpoint, mean, variance_inverse, opacity, l_d, t_ckpt, pixel_sum_grad
             )
         g_mean = g_mean if mean.is_floating_point() else None  # integer means carry no gradient
         return None, None, None, None, g_mean, g_vinv, g_op.reshape(opacity.shape), g_l, None, None

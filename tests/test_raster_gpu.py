@@ -545,30 +545,29 @@ def test_function_forward_backward_in_a_hip_graph(device):
     wimg = sc["wimg"].to(device)
     batch = torch.tensor([n], device=device)
 
-    def step():
-        img = ck.custom_autograd_grouped_cumprod.apply(st["boxsize"], batch, st["start"], st["end"], st["mean"], vinv, op, l_d,
+    def body(v, o, l):
+        img = ck.custom_autograd_grouped_cumprod.apply(st["boxsize"], batch, st["start"], st["end"], st["mean"], v, o, l,
                                                        sc["width"], sc["height"])
-        gv, go, gl = torch.autograd.grad((img * wimg).sum(), (vinv, op, l_d))
-        return img, gv, go, gl
+        return (img * wimg).sum(), img
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with ck.tile_capacity(4 * n + 1024), torch.cuda.stream(side):
-        for _ in range(2):
-            step()  # warm-up on the capture stream
-    torch.cuda.current_stream().wait_stream(side)
+    def step():
+        loss, img = body(vinv, op, l_d)
+        return (img, *torch.autograd.grad(loss, (vinv, op, l_d)))
+
+    eager = step()  # an eager step on the default stream whose outputs (and autograd graph) stay referenced below
+    cap = 4 * n + 1024
+    gs = ck.GraphedStep(body, [vinv, op, l_d], capacity=cap)
     assert not ck.capacity_exceeded()
-    graph = torch.cuda.CUDAGraph()
-    with ck.tile_capacity(4 * n + 1024), torch.cuda.graph(graph, stream=side):
-        outs = step()
     # new parameter values in the captured buffers, then replay: no Python, no host read
     with torch.no_grad():
         op.mul_(0.7).add_(0.1)
         l_d.copy_(torch.rand_like(l_d))
         vinv.mul_(1.3)
-    graph.replay()
+    (_, g_img), g_grads = gs.replay()
     torch.cuda.synchronize()
     assert not ck.capacity_exceeded()
+    outs = (g_img, *g_grads)
+    assert eager[0].grad_fn is not None
     img, gv, go, gl = (t.detach().cpu() for t in outs)
     i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], vinv.detach().cpu(), op.detach().cpu(),
                                                  l_d.detach().cpu(), sc["width"], sc["height"], sc["wimg"])
@@ -580,3 +579,42 @@ def test_function_forward_backward_in_a_hip_graph(device):
     with ck.tile_capacity(50):
         step()
     assert ck.capacity_exceeded()
+    assert not ck.capacity_exceeded()  # read and reset
+
+
+def test_capacity_overflow_is_reported_by_every_replay_of_a_captured_step(device):
+    """the overflow flag of a captured step must not go blind after the first check.  Capture with a bound
+    that fits, let the boxes grow in place (Gaussians move between steps), replay: every replay whose lists outgrow the
+    captured bound reports it, and shrinking the boxes again clears it."""
+    import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(400, 100, 70, 9, 5)
+    n = sc["start"].size(0)
+    st = {k: sc[k].to(device) for k in ("boxsize", "start", "end", "mean")}
+    vinv = sc["vinv"].to(device).clone().requires_grad_(True)
+    op = sc["opacity"].to(device).clone().requires_grad_(True)
+    l_d = sc["l_d"].to(device).clone().requires_grad_(True)
+    wimg = sc["wimg"].to(device)
+    K = raster.bin_tiles(st["start"], st["end"], sc["width"], sc["height"]).n_tile_pairs
+
+    def body(v, o, l):
+        img = ck.custom_autograd_grouped_cumprod.apply(st["boxsize"], None, st["start"], st["end"], st["mean"], v, o, l,
+                                                       sc["width"], sc["height"])
+        return (img * wimg).sum(), img
+
+    gs = ck.GraphedStep(body, [vinv, op, l_d], capacity=K + 8)
+    gs.replay()
+    assert not ck.capacity_exceeded()
+    small = st["end"].clone()
+    st["end"].add_(48).clamp_(max=torch.tensor([sc["width"], sc["height"]], device=device, dtype=st["end"].dtype))
+    assert raster.bin_tiles(st["start"], st["end"], sc["width"], sc["height"]).n_tile_pairs > K + 8
+    for _ in range(3):  # every replay reports, not only the first
+        gs.replay()
+        assert ck.capacity_exceeded()
+    gs.replay()
+    gs.replay()
+    assert ck.capacity_exceeded() and not ck.capacity_exceeded()  # sticky across replays until read
+    st["end"].copy_(small)
+    gs.replay()
+    assert not ck.capacity_exceeded()

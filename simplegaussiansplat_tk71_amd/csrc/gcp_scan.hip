@@ -137,6 +137,7 @@ struct ScanArgs {
   const float* in2;  // grad_out (a3 only)
   const int* key;    // pixel key (a1/a2) or dense group id `inv` (a3)
   const float* carry;  // optional per-group prefix (indexed by `key`, which must then be the dense group id)
+  const int* index;    // INDEXED scans: element i of the scan is in0[index[i]] and its result goes to out[index[i]]
   float* out;
   i64 n;
   i64 ntiles;
@@ -239,6 +240,24 @@ __device__ __forceinline__ int4_t ld4_guard(const int* base, i64 p0, i64 n, int 
   v.w = (p0 + 3 < n) ? base[p0 + 3] : fill;
   return v;
 }
+// INDEXED scans (the sort -> scan -> un-sort sandwich of the reference's _create_alpha_brend, gs_model.py:548-555, in one
+// pass): values are gathered through the sort permutation on the way in and scattered through it on the way out, so
+// neither the sorted copy of the values nor the sorted result ever exists in memory.
+template <bool ALIGNED, bool NT>
+__device__ __forceinline__ float4_t ld4_indexed(const float* src, const int* index, i64 p, int4_t& idx) {
+  idx = ld4<ALIGNED, NT>(index + p);
+  float4_t v; v.x = src[idx.x]; v.y = src[idx.y]; v.z = src[idx.z]; v.w = src[idx.w];
+  return v;
+}
+__device__ __forceinline__ float4_t ld4_indexed_guard(const float* src, const int* index, i64 p0, i64 n, float fill, int4_t& idx) {
+  idx = ld4_guard(index, p0, n, 0);
+  float4_t v;
+  v.x = (p0 + 0 < n) ? src[idx.x] : fill;
+  v.y = (p0 + 1 < n) ? src[idx.y] : fill;
+  v.z = (p0 + 2 < n) ? src[idx.z] : fill;
+  v.w = (p0 + 3 < n) ? src[idx.w] : fill;
+  return v;
+}
 template <bool REV> __device__ __forceinline__ float4_t to_scan_order(float4_t v) {
   if (!REV) return v;
   float4_t r; r.x = v.w; r.y = v.z; r.z = v.y; r.w = v.x;
@@ -274,7 +293,7 @@ __device__ __forceinline__ unsigned long long pack_desc(float agg, unsigned flag
 // ----------------------------------------------------------------------------
 // FIXUP: the follow-up kernel re-runs a tile whose wait for the descriptor tree ran out, with the carry `fix_carry` it
 // took from the (completed) tree: same code, same association, so the tile gets the bits it would have got in time.
-template <int MODE, bool ALIGNED, bool FULL, bool CARRY, bool FIXUP = false>
+template <int MODE, bool ALIGNED, bool FULL, bool CARRY, bool FIXUP = false, bool INDEXED = false>
 __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float* s_wv, int* s_wf,
                                           float* s_tc, int* s_fh, const float fix_carry = 0.0f) {
   typedef Mode<MODE> MD;
@@ -300,6 +319,9 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   float4_t v[kRows];
   int4_t kk[kRows];
   float4_t xp[BWD ? kRows : 1];
+  int4_t ix[INDEXED ? kRows : 1];  // the permutation entries of this lane's elements, memory order
+  static_assert(!(INDEXED && BWD), "the backward has no indexed form");
+  int4_t lb_ix;                    // (look-back gathers: only the values are used)
   i64 p0[kRows];
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
@@ -310,6 +332,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         kk[r] = ld4<ALIGNED, true>(a.key + p0[r]);
         if constexpr (BWD) {
           v[r] = ld4<ALIGNED, true>(a.in2 + p0[r]) * ld4<ALIGNED, true>(a.in1 + p0[r]);
+        } else if constexpr (INDEXED) {
+          v[r] = ld4_indexed<ALIGNED, true>(a.in0, a.index, p0[r], ix[r]);
         } else {
           v[r] = ld4<ALIGNED, true>(a.in0 + p0[r]);
         }
@@ -317,6 +341,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         kk[r] = ld4<ALIGNED>(a.key + p0[r]);
         if constexpr (BWD) {
           v[r] = ld4<ALIGNED>(a.in2 + p0[r]) * ld4<ALIGNED>(a.in1 + p0[r]);
+        } else if constexpr (INDEXED) {
+          v[r] = ld4_indexed<ALIGNED, false>(a.in0, a.index, p0[r], ix[r]);
         } else {
           v[r] = ld4<ALIGNED>(a.in0 + p0[r]);
         }
@@ -329,6 +355,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         const float4_t c = ld4_guard(a.in1, p0[r], n, 0.0f);
         xp[r] = ld4_guard(a.in0, p0[r], n, 1.0f);
         v[r] = g * c;
+      } else if constexpr (INDEXED) {
+        v[r] = ld4_indexed_guard(a.in0, a.index, p0[r], n, id, ix[r]);
       } else {
         v[r] = ld4_guard(a.in0, p0[r], n, id);
       }
@@ -354,10 +382,12 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
     if (!REV) {
       lbk = ld4<ALIGNED>(a.key + lbp);
       if constexpr (BWD) lbv = ld4<ALIGNED>(a.in2 + lbp) * ld4<ALIGNED>(a.in1 + lbp);
+      else if constexpr (INDEXED) lbv = ld4_indexed<ALIGNED, false>(a.in0, a.index, lbp, lb_ix);
       else lbv = ld4<ALIGNED>(a.in0 + lbp);
     } else {
       lbk = ld4_guard(a.key, lbp, n, 0);
       if constexpr (BWD) lbv = ld4_guard(a.in2, lbp, n, 0.0f) * ld4_guard(a.in1, lbp, n, 0.0f);
+      else if constexpr (INDEXED) lbv = ld4_indexed_guard(a.in0, a.index, lbp, n, id, lb_ix);
       else lbv = ld4_guard(a.in0, lbp, n, id);
     }
   }
@@ -494,10 +524,12 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
           if (!REV) {
             ck[c] = ld4<ALIGNED>(a.key + cp[c]);
             if constexpr (BWD) cv[c] = ld4<ALIGNED>(a.in2 + cp[c]) * ld4<ALIGNED>(a.in1 + cp[c]);
+            else if constexpr (INDEXED) cv[c] = ld4_indexed<ALIGNED, false>(a.in0, a.index, cp[c], lb_ix);
             else cv[c] = ld4<ALIGNED>(a.in0 + cp[c]);
           } else {
             ck[c] = ld4_guard(a.key, cp[c], n, 0);
             if constexpr (BWD) cv[c] = ld4_guard(a.in2, cp[c], n, 0.0f) * ld4_guard(a.in1, cp[c], n, 0.0f);
+            else if constexpr (INDEXED) cv[c] = ld4_indexed_guard(a.in0, a.index, cp[c], n, id, lb_ix);
             else cv[c] = ld4_guard(a.in0, cp[c], n, id);
           }
         }
@@ -664,7 +696,12 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       y.w = y.w / (xp[r].w != 0.0f ? xp[r].w : 1e-8f);
     }
     y = to_scan_order<REV>(y);  // involution: back to memory order
-    if (FULL) {
+    if constexpr (INDEXED) {  // un-sort: through the permutation (gs_model.py:555 `output[torch.argsort(index)]`)
+      if (FULL || p0[r] + 0 < n) a.out[ix[r].x] = y.x;
+      if (FULL || p0[r] + 1 < n) a.out[ix[r].y] = y.y;
+      if (FULL || p0[r] + 2 < n) a.out[ix[r].z] = y.z;
+      if (FULL || p0[r] + 3 < n) a.out[ix[r].w] = y.w;
+    } else if (FULL) {
       st4<ALIGNED>(a.out + p0[r], y);
     } else {
       if (p0[r] + 0 < n) a.out[p0[r] + 0] = y.x;
@@ -679,8 +716,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
 
 // Forward modes: six blocks per CU (<= 80 VGPRs), which the rare descriptor walk must not cost; the reverse modes are
 // left to the register allocator (the backward holds three arrays per element and runs at three blocks per CU).
-template <int MODE, bool ALIGNED, bool CARRY>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(Mode<MODE>::kRev ? 1 : 6, Mode<MODE>::kRev ? 8 : 6)))
+template <int MODE, bool ALIGNED, bool CARRY, bool INDEXED = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((Mode<MODE>::kRev || INDEXED) ? 1 : 6, (Mode<MODE>::kRev || INDEXED) ? 8 : 6)))
 void gcp_scan_main(const ScanArgs a) {
   __shared__ float s_wv[kWaves];
   __shared__ int s_wf[kWaves + 2];
@@ -688,8 +725,8 @@ void gcp_scan_main(const ScanArgs a) {
   __shared__ int s_fh[kWaves];
   const i64 lt = logical_tile((i64)blockIdx.x, a.ntiles, a.xcd_remap);
   const i64 pt = Mode<MODE>::kRev ? (a.ntiles - 1 - lt) : lt;
-  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true, CARRY>(a, lt, s_wv, s_wf, s_tc, s_fh);
-  else scan_tile<MODE, ALIGNED, false, CARRY>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true, CARRY, false, INDEXED>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  else scan_tile<MODE, ALIGNED, false, CARRY, false, INDEXED>(a, lt, s_wv, s_wf, s_tc, s_fh);
 }
 
 // ----------------------------------------------------------------------------
@@ -771,7 +808,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
 // wrote — the set the next launch on this workspace will publish into — and (ii) counts itself done; the last block
 // to finish advances the launch counter, which flips the sets.  Nobody reads the other set or the counter's parity
 // after that point in this launch, so neither needs a barrier.
-template <int MODE, bool CARRY>
+template <int MODE, bool CARRY, bool INDEXED = false>
 __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
   typedef Mode<MODE> MD;
   __shared__ float s_wv[kWaves];
@@ -842,7 +879,7 @@ __global__ __launch_bounds__(kThreads) void gcp_fallback(const ScanArgs a) {
           __syncthreads();
           const float c = s_carry;
           // guarded dword form of the tile routine: the same arithmetic as the vector form on any alignment and tile
-          scan_tile<MODE, false, false, CARRY, true>(a, lt, s_wv, s_wf, s_tc, s_fh, c);
+          scan_tile<MODE, false, false, CARRY, true, INDEXED>(a, lt, s_wv, s_wf, s_tc, s_fh, c);
           __syncthreads();
         }
         __syncthreads();
@@ -944,7 +981,7 @@ int env_int(const char* name, int dflt) {
 
 template <int MODE>
 int launch_scan(const float* in0, const float* in1, const float* in2, const int* key, float* out,
-                i64 n, void* ws, size_t ws_bytes, void* stream_, const float* carry = nullptr) {
+                i64 n, void* ws, size_t ws_bytes, void* stream_, const float* carry = nullptr, const int* index = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n == 0) return GCP_OK;
@@ -954,7 +991,7 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   // storing its outputs, so an output range that shares bytes with an input range races between blocks.
   {
     const uintptr_t o0 = (uintptr_t)out, o1 = o0 + (uintptr_t)n * 4u;
-    const void* ins[4] = {in0, in1, in2, key};
+    const void* ins[5] = {in0, in1, in2, key, index};
     for (const void* q : ins) {
       const uintptr_t q0 = (uintptr_t)q;
       if (q && o0 < q0 + (uintptr_t)n * 4u && q0 < o1) return GCP_ERR_INVALID_ARGUMENT;
@@ -972,7 +1009,7 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   }
   char* p = (char*)ws;
   ScanArgs a;
-  a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry;
+  a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry; a.index = index;
   a.n = n; a.ntiles = ntiles;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
   a.desc_sets = (unsigned long long*)p;
@@ -985,13 +1022,18 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
 
   uintptr_t al = (uintptr_t)in0 | (uintptr_t)key | (uintptr_t)out;
   if (Mode<MODE>::kBwd) al |= (uintptr_t)in1 | (uintptr_t)in2;
+  if (index) al |= (uintptr_t)index;
   const bool aligned = (al & 15u) == 0;
 
   const dim3 grid((unsigned)ntiles), block(kThreads);
   if constexpr (Mode<MODE>::kBwd) {
-    if (carry) return GCP_ERR_INVALID_ARGUMENT;
+    if (carry || index) return GCP_ERR_INVALID_ARGUMENT;
     if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false>), grid, block, 0, stream, a);
+  } else if (index) {
+    if (carry) return GCP_ERR_INVALID_ARGUMENT;
+    if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false, true>), grid, block, 0, stream, a);
   } else if (carry) {
     if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((gcp_scan_main<MODE, false, true>), grid, block, 0, stream, a);
@@ -1006,7 +1048,8 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
     // grid is small unless the descriptor walk is switched off and the kernel has real work on every long group
     const i64 want = a.patience < 0 ? kFixBlocks : kFixBlocksQuiet;
     const unsigned fb = (unsigned)(ntiles < want ? ntiles : want);
-    if (carry) hipLaunchKernelGGL((gcp_fallback<MODE, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
+    if (index) hipLaunchKernelGGL((gcp_fallback<MODE, false, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
+    else if (carry) hipLaunchKernelGGL((gcp_fallback<MODE, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
     else hipLaunchKernelGGL((gcp_fallback<MODE, false>), dim3(fb), dim3(kThreads), 0, stream, a);
     GCP_HIP(hipGetLastError());
   }
@@ -1060,6 +1103,24 @@ int gcp_cumsum_forward(const float* x, const int32_t* key, float* y, int64_t n, 
 int gcp_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t n, void* ws,
                        size_t ws_bytes, void* stream) {
   return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, key, y, n, ws, ws_bytes, stream);
+}
+
+int gcp_cumprod_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMPROD_FWD>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
+}
+
+int gcp_cumsum_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMSUM_FWD>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
+}
+
+int gcp_cumsum_reverse_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
 }
 
 int gcp_cumprod_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,

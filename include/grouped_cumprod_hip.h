@@ -56,7 +56,7 @@ extern "C" {
 #define GCP_ERR_WORKSPACE 2        /* workspace too small / misaligned */
 #define GCP_ERR_HIP 3              /* a HIP call failed: see gcp_last_hip_error() */
 
-#define GCP_ABI_VERSION 2
+#define GCP_ABI_VERSION 3
 
 /* ABI version of the loaded library (== GCP_ABI_VERSION it was built with). */
 int gcp_abi_version(void);
@@ -126,6 +126,22 @@ int gcp_cumprod_backward(const float* param, const float* param_cumprod,
  */
 int gcp_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t n,
                        void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * INDEXED forms: the sort -> scan -> un-sort sandwich of _create_alpha_brend (reference: gs_model.py:548
+ * `anti_opacity[index]`, :551/:553 the scan, :555 `output[torch.argsort(index)]`) in ONE pass.  `x` and `y` are in the
+ * caller's ORIGINAL pair order, `sorted_key` / `index` are what gcp_sort_pairs_u32 / gcp_sort_rects returned
+ * (sorted_key[i] = key of original element index[i]; `index` a permutation of 0..n-1):
+ *   y[index[i]] = scan over i, inside runs of equal adjacent sorted_key, of x[index[i]].
+ * Neither the sorted copy of the values nor the sorted result is materialised.  Same association, determinism and
+ * workspace rules as the plain scans.  Traffic: 16 B / element (key 4, index 4, gathered value 4, scattered result 4).
+ */
+int gcp_cumprod_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                                void* ws, size_t ws_bytes, void* stream);
+int gcp_cumsum_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                               void* ws, size_t ws_bytes, void* stream);
+int gcp_cumsum_reverse_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
+                               void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Exact chunk carry.  Same scans, but group g starts from carry[g]
@@ -259,6 +275,27 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
 size_t gcp_sort_workspace_bytes(int64_t n);
 int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out,
                        int32_t* index_out, void* ws, size_t ws_bytes, void* stream);
+/* The same sort with the reference's pixel key computed on the fly from its rect list (gs_model.py:538-541, :546:
+ * key = y * 10000 + x of rects_xy[i] = (x, y)): the int32 key array of `unique()` never exists.  keys_out receives
+ * the sorted keys (what `sorted_inv` is at gs_model.py:547), index_out the permutation.  key_bits must cover
+ * height * 10000 + width (24 for 1920x1080, 25 for 3840x2160). */
+int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
+                   void* ws, size_t ws_bytes, void* stream);
+/* max over i of (y_i * 10000 + x_i) and min over i of min(x_i, y_i), written to out_dev[0], out_dev[1] (device int32[2]):
+ * what a caller needs to choose key_bits when it does not know the image size. */
+int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream);
+
+/* The tail of _create_alpha_brend (gs_model.py:557-564) on the un-sorted inclusive scan values, elements [begin, end)
+ * of the original pair order (the reference's `cutting_number` slices, :557-559):
+ *   keep[j]   = inclusive[begin + j] != 0                                   (:560, :575-578)
+ *   values[k] = inclusive[i] / self[i] (mode 0, :562) or inclusive[i] - self[i] (mode 1, :564)
+ *               for the k-th kept i, in order                               (the boolean-mask compaction)
+ * count_dev[0] (device int32) receives the number of kept elements.  Stable stream compaction in two launches (per-tile
+ * counts, then ranks from one exclusive scan of them): no atomics, deterministic.  values needs room for end - begin
+ * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 17 B / element. */
+size_t gcp_compact_workspace_bytes(int64_t n);
+int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
+                       uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* The index plumbing of _create_alpha_brend around the scan, with the int32 permutation of gcp_sort_pairs_u32:
  * gcp_gather_f32: dst[i] = src[index[i]] (gs_model.py:548); gcp_unsort_finish: full[index[i]] = inclusive[i] / x_i

@@ -26,6 +26,9 @@ SIGNATURES = {
     "gcp_cumprod_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_forward": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_reverse": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumprod_forward_indexed": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_forward_indexed": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _c_void_p, _sz, _c_void_p]),
+    "gcp_cumsum_reverse_indexed": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumprod_forward_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_forward_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
     "gcp_cumsum_reverse_carry": (ctypes.c_int, [_c_void_p] * 4 + [_i64, _i64, _c_void_p, _sz, _c_void_p]),
@@ -69,6 +72,10 @@ SIGNATURES = {
     "gcp_unsort_finish": (ctypes.c_int, [_c_void_p] * 5 + [_i64, _i32, _c_void_p]),
     "gcp_sort_workspace_bytes": (_sz, [_i64]),
     "gcp_sort_pairs_u32": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
+    "gcp_sort_rects": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
+    "gcp_rects_key_range": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _c_void_p]),
+    "gcp_compact_workspace_bytes": (_sz, [_i64]),
+    "gcp_compact_finish": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_box_sizes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p]),
     "gcp_expand_rects": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p]),
     "gcp_pixel_lists_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5),
@@ -83,7 +90,7 @@ SIGNATURES = {
     "gcp_project_backward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32] + [_c_void_p] * 10),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -43,6 +43,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gcp_device.hpp"
 #include "grouped_cumprod_hip.h"
@@ -217,25 +218,52 @@ __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int 
 // ------------------------------------------------------------------------------------------
 constexpr int kSortChunk = 4096;    // keys per radix-sort block
 
+// RECTS: `key` points at the reference's rect list, int32 (x, y) per pair, and the key is y * 10000 + x
+// (gs_model.py:538-541) computed on the fly — the key array of `unique()` never exists in memory.
+template <bool RECTS>
+__device__ __forceinline__ unsigned load_key(const unsigned* key, i64 i) {
+  if (!RECTS) return key[i];
+  const int2 r = reinterpret_cast<const int2*>(key)[i];
+  return (unsigned)(r.y * 10000 + r.x);
+}
+
+// Chunk (4096 keys) of this block.  Blocks are dealt round-robin over the 8 XCDs; with the remap XCD x takes the x-th
+// CONTIGUOUS eighth of the chunks, so the blocks that run on one XCD at the same time hold neighbouring chunks: their
+// runs inside every digit bucket are adjacent in the destination, and the partial cache lines at the run ends merge in
+// that XCD's L2 instead of being written back half-filled from two.  -1: no such chunk (the grid is rounded up to 8).
+__device__ __forceinline__ i64 sort_chunk(i64 b, i64 nblk, int xcd_remap) {
+  if (!xcd_remap) return b < nblk ? b : -1;
+  const i64 per = (nblk + 7) >> 3;
+  const i64 c = (b & 7) * per + (b >> 3);
+  return ((b >> 3) < per && c < nblk) ? c : -1;
+}
+inline unsigned sort_grid(i64 nblk, int xcd_remap) { return (unsigned)(xcd_remap ? ((nblk + 7) >> 3) * 8 : nblk); }
+
 // n_dev (optional): the number of keys lives on the device (capture-safe binning); n is then only the bound the grid was
 // sized for, and blocks past the real count contribute empty histograms / copy nothing
-__global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk, const int* n_dev) {
+template <bool RECTS>
+__global__ __launch_bounds__(256) void k_sort_hist(const unsigned* key, i64 n, int shift, int* hist, int nblk, const int* n_dev,
+                                                   int xcd_remap) {
   __shared__ int h[256];
+  const i64 chunk = sort_chunk(blockIdx.x, nblk, xcd_remap);
+  if (chunk < 0) return;
   if (n_dev) n = min(n, (i64)*n_dev);
   h[threadIdx.x] = 0;
   __syncthreads();
-  const i64 base = (i64)blockIdx.x * kSortChunk;
+  const i64 base = chunk * kSortChunk;
 #pragma unroll 4
   for (int i = threadIdx.x; i < kSortChunk; i += 256)
-    if (base + i < n) atomicAdd(&h[(key[base + i] >> shift) & 255u], 1);
+    if (base + i < n) atomicAdd(&h[(load_key<RECTS>(key, base + i) >> shift) & 255u], 1);
   __syncthreads();
-  hist[(i64)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  hist[(i64)threadIdx.x * nblk + chunk] = h[threadIdx.x];
 }
 
-template <bool FIRST>  // FIRST: the payload is the element's own index
+template <bool FIRST, bool RECTS = false>  // FIRST: the payload is the element's own index
 __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const unsigned* val, unsigned* key_out,
                                                        unsigned* val_out, i64 n, int shift, const int* hist_excl,
-                                                       int nblk, const int* n_dev) {
+                                                       int nblk, const int* n_dev, int xcd_remap) {
+  const i64 chunk = sort_chunk(blockIdx.x, nblk, xcd_remap);
+  if (chunk < 0) return;
   if (n_dev) n = min(n, (i64)*n_dev);
   __shared__ unsigned s_key[kSortChunk];
   __shared__ unsigned s_val[kSortChunk];
@@ -245,7 +273,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int d = lane; d < 256; d += 64) off[w][d] = 0;
   __syncthreads();
-  const i64 bbase = (i64)blockIdx.x * kSortChunk;
+  const i64 bbase = chunk * kSortChunk;
   const i64 wbase = bbase + (i64)w * (kSortChunk / 4);
   constexpr int kSteps = kSortChunk / 4 / 64;  // 16
   unsigned k[kSteps], v[kSteps];
@@ -253,7 +281,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
   for (int st = 0; st < kSteps; ++st) {  // (A)
     const i64 i = wbase + st * 64 + lane;
     const bool valid = i < n;
-    k[st] = valid ? key[i] : 0u;
+    k[st] = valid ? load_key<RECTS>(key, i) : 0u;
     v[st] = FIRST ? (unsigned)i : (valid ? val[i] : 0u);
     if (valid) atomicAdd(&off[w][(k[st] >> shift) & 255u], 1);  // counts only: order-independent
   }
@@ -266,7 +294,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
     off[1][tid] = lstart + c0;
     off[2][tid] = lstart + c0 + c1;
     off[3][tid] = lstart + c0 + c1 + c2;
-    gdelta[tid] = hist_excl[(i64)tid * nblk + blockIdx.x] - lstart;
+    gdelta[tid] = hist_excl[(i64)tid * nblk + chunk] - lstart;
   }
   __syncthreads();
 #pragma unroll
@@ -764,6 +792,108 @@ __global__ void k_unsort_finish(const float* __restrict__ incl, const float* __r
   keep[o] = v != 0.0f ? 1 : 0;
 }
 
+// max of the pixel keys and min of the coordinates of a rect list (integer max / min: order-independent)
+__global__ __launch_bounds__(256) void k_rects_key_range(const int* rects, i64 n, int* out /*[2] = {max key, min coordinate}*/) {
+  __shared__ int s_mx[4], s_mn[4];
+  int mx = 0, mn = 0x7fffffff;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) {
+    const int2 r = reinterpret_cast<const int2*>(rects)[i];
+    mx = max(mx, r.y * 10000 + r.x);
+    mn = min(mn, min(r.x, r.y));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, __shfl_xor(mx, o));
+    mn = min(mn, __shfl_xor(mn, o));
+  }
+  if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_mn[threadIdx.x >> 6] = mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(out, max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])));
+    atomicMin(out + 1, min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])));
+  }
+}
+
+// ---- the tail of _create_alpha_brend (gs_model.py:557-564): `!= 0` mask, boolean-mask compaction, / self or - self ----
+// One 256-thread block per tile of kCompactTile elements of the ORIGINAL pair order; wave w owns elements
+// [1024 w, 1024 w + 1024) of the tile as 4 rows of 64 lanes x 4 consecutive elements (16-byte loads).  WRITE = false:
+// the tile's kept count.  WRITE = true: every kept element's rank = tile offset (exclusive scan of the counts) + kept
+// elements before it in the tile (per-lane popcounts -> wave prefix in DPP -> 4 LDS words), its value written to that
+// slot — neighbouring lanes write neighbouring slots — and the mask as one packed word per lane.
+constexpr int kCompactTile = 4096;
+template <bool VEC, bool WRITE>
+__global__ __launch_bounds__(256) void k_compact(const float* __restrict__ incl, const float* __restrict__ self, i64 n, int mode,
+                                                 int* __restrict__ cnt, const int* __restrict__ off, float* __restrict__ values,
+                                                 unsigned char* __restrict__ keep, int* __restrict__ count_dev) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 base = (i64)blockIdx.x * kCompactTile + (i64)w * 1024;
+  float v[4][4], x[4][4];
+  unsigned m[4];
+  int c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    if (VEC && p + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4*>(incl + p);
+      v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w;
+      if (WRITE) {
+        const float4 b = *reinterpret_cast<const float4*>(self + p);
+        x[r][0] = b.x; x[r][1] = b.y; x[r][2] = b.z; x[r][3] = b.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[r][k] = (p + k < n) ? incl[p + k] : 0.0f;
+        if (WRITE) x[r][k] = (p + k < n) ? self[p + k] : 1.0f;
+      }
+    }
+    m[r] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[r] |= (v[r][k] != 0.0f ? 1u : 0u) << k;  // NaN != 0 is true, as in torch (gs_model.py:577)
+    c[r] = __builtin_popcount(m[r]);
+  }
+  // kept elements before this lane inside the wave's 1024: rows in order, lanes in order inside a row
+  int before[4];
+  int wtot = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int inc = wave_incl_scan_i(c[r]);
+    before[r] = wtot + inc - c[r];
+    wtot += __builtin_amdgcn_readlane(inc, 63);
+  }
+  if (lane == 0) s_w[w] = wtot;
+  __syncthreads();
+  if (!WRITE) {
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return;
+  }
+  int woff = off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < w) woff += s_w[j];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count_dev[0] = off[blockIdx.x] + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    int o = woff + before[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((m[r] >> k) & 1u) {
+        values[o] = mode == 0 ? v[r][k] / x[r][k] : v[r][k] - x[r][k];
+        ++o;
+      }
+    }
+    if (VEC && p + 3 < n) {
+      // bytes 0/1 per element, memory order: bit k of m -> byte k
+      *reinterpret_cast<unsigned*>(keep + p) = (m[r] & 1u) | ((m[r] & 2u) << 7) | ((m[r] & 4u) << 14) | ((m[r] & 8u) << 21);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k < n) keep[p + k] = (unsigned char)((m[r] >> k) & 1u);
+    }
+  }
+}
+
 __global__ void k_box_sizes(const int* start, const int* end, i64 n, int W, int H, int* size) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
@@ -865,12 +995,12 @@ static int bin_fill(const int32_t* start_xy, const int32_t* end_xy, int64_t n_ga
   unsigned *ks = keyA, *vs = valA, *kd = keyB, *vd = valB;
   for (int pass = 0; pass < passes; ++pass) {
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks, K, shift, hist, (int)nblk, n_dev);
+    hipLaunchKernelGGL((k_sort_hist<false>), dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks, K, shift, hist, (int)nblk, n_dev, 0);
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
     if (st != GCP_OK) return st;
     hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, (const unsigned*)ks,
-                       (const unsigned*)vs, kd, vd, K, shift, (const int*)hist_ex, (int)nblk, n_dev);
+                       (const unsigned*)vs, kd, vd, K, shift, (const int*)hist_ex, (int)nblk, n_dev, 0);
     GCP_HIP(hipGetLastError());
     unsigned* t;
     t = ks; ks = kd; kd = t;
@@ -1046,14 +1176,15 @@ size_t gcp_sort_workspace_bytes(int64_t n) {
   return b;
 }
 
-int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
-                       void* ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
+                     void* ws, size_t ws_bytes, hipStream_t stream) {
   if (n < 0 || n > 0x7fffffffLL || key_bits < 1 || key_bits > 32) return GCP_ERR_INVALID_ARGUMENT;
   if (n == 0) return GCP_OK;
   if (!keys_in || !keys_out || !index_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_sort_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  static const int xcd_remap = [] { const char* e = getenv("GCP_SORT_XCD"); return (e && *e) ? atoi(e) : 1; }();
   const i64 nblk = (n + kSortChunk - 1) / kSortChunk;
+  const dim3 grid(sort_grid(nblk, xcd_remap)), block(256);
   char* p = (char*)ws;
   unsigned* keyY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
   unsigned* valY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
@@ -1065,25 +1196,91 @@ int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uin
   const int passes = (key_bits + 7) / 8;
   const unsigned* ks = keys_in;
   const unsigned* vs = nullptr;
+  const int* no_count = nullptr;
   for (int pass = 0; pass < passes; ++pass) {
     const bool to_x = ((passes - 1 - pass) & 1) == 0;  // the last pass lands in the caller's buffers
     unsigned* kd = to_x ? keyX : keyY;
     unsigned* vd = to_x ? valX : valY;
     const int shift = 8 * pass;
-    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)nblk), dim3(256), 0, stream, ks, (i64)n, shift, hist, (int)nblk, (const int*)nullptr);
+    if (pass == 0 && rects) hipLaunchKernelGGL((k_sort_hist<true>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nblk, no_count, xcd_remap);
+    else hipLaunchKernelGGL((k_sort_hist<false>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nblk, no_count, xcd_remap);
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
     if (st != GCP_OK) return st;
-    if (pass == 0)
-      hipLaunchKernelGGL((k_sort_scatter<true>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
-                         (const int*)hist_ex, (int)nblk, (const int*)nullptr);
+    if (pass == 0 && rects)
+      hipLaunchKernelGGL((k_sort_scatter<true, true>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nblk, no_count, xcd_remap);
+    else if (pass == 0)
+      hipLaunchKernelGGL((k_sort_scatter<true, false>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nblk, no_count, xcd_remap);
     else
-      hipLaunchKernelGGL((k_sort_scatter<false>), dim3((unsigned)nblk), dim3(256), 0, stream, ks, vs, kd, vd, (i64)n, shift,
-                         (const int*)hist_ex, (int)nblk, (const int*)nullptr);
+      hipLaunchKernelGGL((k_sort_scatter<false, false>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nblk, no_count, xcd_remap);
     GCP_HIP(hipGetLastError());
     ks = kd;
     vs = vd;
   }
+  return GCP_OK;
+}
+
+int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
+                       void* ws, size_t ws_bytes, void* stream_) {
+  return sort_impl(keys_in, false, n, key_bits, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out, void* ws,
+                   size_t ws_bytes, void* stream_) {
+  return sort_impl((const unsigned*)rects_xy, true, n, key_bits, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || !out_dev) return GCP_ERR_INVALID_ARGUMENT;
+  const int init[2] = {0, 0x7fffffff};
+  GCP_HIP(hipMemcpyAsync(out_dev, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  if (n == 0) return GCP_OK;
+  if (!rects_xy) return GCP_ERR_INVALID_ARGUMENT;
+  i64 blocks = (n + 4095) / 4096;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_rects_key_range, dim3((unsigned)blocks), dim3(256), 0, stream, rects_xy, (i64)n, out_dev);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+size_t gcp_compact_workspace_bytes(int64_t n) {
+  const int64_t nb = ((n > 0 ? n : 1) + kCompactTile - 1) / kCompactTile + 1;
+  return align256((size_t)(nb + 1) * sizeof(int)) * 2 + gcp_scan_i32_workspace_bytes(nb);
+}
+
+int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
+                       uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (begin < 0 || end < begin || end - begin > 0x7fffffffLL || (mode != 0 && mode != 1) || !count_dev) return GCP_ERR_INVALID_ARGUMENT;
+  const i64 n = end - begin;
+  if (n == 0) {
+    GCP_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), stream));
+    return GCP_OK;
+  }
+  if (!inclusive || !self || !values || !keep || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_compact_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  const i64 nb = (n + kCompactTile - 1) / kCompactTile;
+  char* p = (char*)ws;
+  int* cnt = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  int* off = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  int* sws = (int*)p;
+  const bool vec = (((uintptr_t)(inclusive + begin) | (uintptr_t)(self + begin) | (uintptr_t)keep) & 15u) == 0;
+  if (vec) hipLaunchKernelGGL((k_compact<true, false>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode, cnt,
+                              (const int*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
+  else hipLaunchKernelGGL((k_compact<false, false>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode, cnt,
+                          (const int*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
+  GCP_HIP(hipGetLastError());
+  const int st = launch_excl_scan(cnt, off, nb, sws, stream);
+  if (st != GCP_OK) return st;
+  if (vec) hipLaunchKernelGGL((k_compact<true, true>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode,
+                              (int*)nullptr, (const int*)off, values, keep, count_dev);
+  else hipLaunchKernelGGL((k_compact<false, true>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode,
+                          (int*)nullptr, (const int*)off, values, keep, count_dev);
+  GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 

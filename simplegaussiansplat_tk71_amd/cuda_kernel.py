@@ -15,14 +15,15 @@ Deliberate differences from the reference, all result-preserving:
   * `torch.sort(..., stable=True)`: depth order inside a pixel is carried only by
     sort stability; the reference calls torch.sort without it (gs_model.py:547),
     which is stable on CUDA in practice and NOT on CPU for small inputs.
-  * the sort itself is the library's own stable LSD radix sort (raster.stable_sort_keys ->
-    gcp_sort_pairs_u32: only the significant key bits, int32 payload, coalesced scatters;
-    bit-identical to torch.sort(stable=True) and 1.7x faster at 1.6e8 keys).
-  * the un-sort `output[torch.argsort(index)]` (gs_model.py:555, a second radix
-    sort) is the equivalent scatter through the permutation, fused in ONE kernel
-    (gcp_unsort_finish) with the `/ self` or `- self` step and the `!= 0` test — those
-    commute with the compaction that the reference applies first (:560-564); the gather
-    (:548) uses the int32 permutation directly (gcp_gather_f32).
+  * the sort itself is the library's own stable LSD radix sort (raster.sort_rects -> gcp_sort_rects: the
+    pixel key is computed from `rects` inside the first pass, only the significant key bits are sorted,
+    int32 payload; bit-identical to torch.sort(stable=True) of the keys).
+  * gather (gs_model.py:548), scan (:551/:553) and un-sort `output[torch.argsort(index)]` (:555, a
+    second radix sort in the reference) are ONE indexed scan (gcp_cum*_indexed): values are gathered
+    through the permutation on the way in and the inclusive results scattered through it on the way out.
+  * the `!= 0` mask, the boolean-mask compaction and `/ self` | `- self` (:560-564) are one stable
+    stream compaction over the original order (gcp_compact_finish); the element-wise step commutes with
+    the compaction the reference applies first.
   * grad_cumsum's flip / scan / flip is one reverse scan on the same sorted keys.
 """
 import contextlib
@@ -38,6 +39,7 @@ __all__ = [
     "grouped_cumprod",
     "grouped_cumsum",
     "unique",
+    "pixel_key_bits",
     "create_alpha_brend",
     "create_alpha_blend",
     "grad_cumsum",
@@ -207,43 +209,47 @@ def unique(rects):
         return rects[:, 1] * 10000 + rects[:, 0]
 
 
-def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None):
+def pixel_key_bits(image_width, image_height):
+    """Bits of the largest pixel key y*10000 + x of an image (24 at 1920x1080, 25 at 3840x2160): pass it as `key_bits` to
+    `create_alpha_brend` / `grad_cumsum` and the sort never has to read the key range back from the device."""
+    return max(1, (int(image_height) * 10000 + int(image_width)).bit_length())
+
+
+def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bits=None):
     """Per-pixel exclusive transmittance (flag="cumprod") or exclusive prefix sum
     (flag="cumsum") of `anti_opacity`, returned in the ORIGINAL pair order.
 
-    reference: gs_model.py:544-566.  Steps kept one for one: key, stable sort, gather,
-    grouped scan, un-sort, drop `cutting_number` carry rows, compact the entries whose
-    inclusive value is exactly 0 (:560, :575-578), then inclusive / self (:562) or
-    inclusive - self (:564).  Returns [values, mask].
-    """
+    reference: gs_model.py:544-566.  Same steps, same results, three stages instead of ten passes over M-length arrays:
+      1. key + stable sort (:546-547): the pixel key is computed inside the first radix pass straight from `rects`;
+      2. gather, grouped scan, un-sort (:548-555): ONE indexed scan — values gathered through the permutation on the
+         way in, inclusive results scattered through it on the way out;
+      3. drop `cutting_number` carry rows, compact the entries whose inclusive value is exactly 0 (:557-560, :575-578),
+         then inclusive / self (:562) or inclusive - self (:564): ONE stable stream compaction in original order.
+    Returns [values, mask].  `key_bits` (keyword-only extension): `pixel_key_bits(width, height)`; None reads the key
+    range back once."""
     with torch.no_grad():
-        inv = unique(rects)
-        sorted_inv, index = _raster.stable_sort_keys(inv.contiguous())  # int32 permutation
+        sorted_inv, index = _raster.sort_rects(rects, key_bits)
         return _scan_unsort_compact(sorted_inv, index, anti_opacity, flag, cutting_number)
 
 
 def _scan_unsort_compact(sorted_key, index, anti_opacity, flag, cutting_number=None):
-    """Everything of _create_alpha_brend after the sort (gs_model.py:548-566) on the HIP library: gather, grouped
-    scan, then ONE kernel for un-sort + (/ self | - self) + the != 0 test; only the final compaction is a torch op.
+    """Everything of _create_alpha_brend after the sort (gs_model.py:548-566) on the HIP library.
     flag "cumsum_reverse" is grad_cumsum's suffix form (gs_model.py:716-722), whose carry rows sit at the END."""
     if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
         raise ValueError(flag)
-    anti_opacity = anti_opacity.contiguous()
-    sorted_x = _raster.gather_f32(anti_opacity, index)
-    output = torch.empty_like(sorted_x)
+    anti_opacity = anti_opacity.detach().contiguous()
+    inclusive = torch.empty_like(anti_opacity)
     if flag == "cumprod":
-        _ext.grouped_cumprod_forward(sorted_x, sorted_key, output)
+        _ext.grouped_cumprod_forward_indexed(anti_opacity, sorted_key, index, inclusive)
     elif flag == "cumsum":
-        _ext.grouped_cumsum_forward(sorted_x, sorted_key, output)
+        _ext.grouped_cumsum_forward_indexed(anti_opacity, sorted_key, index, inclusive)
     else:
-        _ext.grouped_cumsum_reverse(sorted_x, sorted_key, output)
-    full, keep = _raster.unsort_finish(output, sorted_x, index, 0 if flag == "cumprod" else 1)
-    if cutting_number:
-        if flag == "cumsum_reverse":
-            full, keep = full[: full.numel() - cutting_number], keep[: keep.numel() - cutting_number]
-        else:
-            full, keep = full[cutting_number:], keep[cutting_number:]
-    return [full[keep], keep]
+        _ext.grouped_cumsum_reverse_indexed(anti_opacity, sorted_key, index, inclusive)
+    n = anti_opacity.numel()
+    cut = int(cutting_number) if cutting_number else 0
+    begin, end = (0, n - cut) if flag == "cumsum_reverse" else (cut, n)
+    values, keep = _raster.compact_finish(inclusive, anti_opacity, 0 if flag == "cumprod" else 1, begin, end)
+    return [values, keep]
 
 
 create_alpha_blend = create_alpha_brend  # spelling alias
@@ -261,7 +267,7 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
         return _scan_unsort_compact(pl.pair_key, pl.pair_index, anti_opacity, flag)
 
 
-def grad_cumsum(rects, grad, cutting_number=None):
+def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None):
     """Per-pixel exclusive SUFFIX sum of `grad` in original pair order.
 
     reference: gs_model.py:716-722 (flip, _create_alpha_brend(flag="cumsum"), flip).
@@ -272,8 +278,7 @@ def grad_cumsum(rects, grad, cutting_number=None):
     returned in ORIGINAL order (the reference leaves it flipped).
     """
     with torch.no_grad():
-        inv = unique(rects)
-        sorted_inv, index = _raster.stable_sort_keys(inv.contiguous())
+        sorted_inv, index = _raster.sort_rects(rects, key_bits)
         return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
 
 

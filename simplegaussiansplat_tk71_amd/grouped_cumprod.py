@@ -26,6 +26,9 @@ __all__ = [
     "grouped_cumsum_forward",
     "grouped_cumprod_backward",
     "grouped_cumsum_reverse",
+    "grouped_cumprod_forward_indexed",
+    "grouped_cumsum_forward_indexed",
+    "grouped_cumsum_reverse_indexed",
     "grouped_cumprod_forward_carry",
     "grouped_cumsum_forward_carry",
     "grouped_cumsum_reverse_carry",
@@ -125,6 +128,37 @@ def grouped_cumsum_reverse(x, key, out):
     """Suffix sums inside each run: flip -> grouped_cumsum_forward -> flip of the
     reference (gs_model.py:716-722) in one pass.  Not in the reference module."""
     _forward("gcp_cumsum_reverse", x, key, out)
+
+
+def _forward_indexed(fn_name, x, sorted_key, index, y):
+    _require(isinstance(sorted_key, torch.Tensor), "sorted_key: expected a torch.Tensor")
+    n = sorted_key.numel()
+    dev = sorted_key.device
+    _check_tensor(sorted_key, "sorted_key", torch.int32, dev)
+    _check_tensor(index, "index", torch.int32, dev, n)
+    _check_tensor(x, "x", torch.float32, dev, n)
+    _check_tensor(y, "out", torch.float32, dev, n)
+    if n == 0:
+        return
+    _no_alias(y, "out", (x, "x"), (sorted_key, "sorted_key"), (index, "index"))
+    _launch(fn_name, dev, n, (x.data_ptr(), sorted_key.data_ptr(), index.data_ptr(), y.data_ptr()))
+
+
+def grouped_cumprod_forward_indexed(x, sorted_key, index, out):
+    """out[index[i]] = running product, inside runs of equal adjacent sorted_key, of x[index[i]]: gather, grouped scan and
+    un-sort of `_create_alpha_brend` (gs_model.py:548-555) in one pass; `x` / `out` in the original pair order,
+    `sorted_key` / `index` from the stable sort of the pixel keys.  `index` must be a permutation (not checked).  Not in
+    the reference module."""
+    _forward_indexed("gcp_cumprod_forward_indexed", x, sorted_key, index, out)
+
+
+def grouped_cumsum_forward_indexed(x, sorted_key, index, out):
+    _forward_indexed("gcp_cumsum_forward_indexed", x, sorted_key, index, out)
+
+
+def grouped_cumsum_reverse_indexed(x, sorted_key, index, out):
+    """Suffix-sum form (grad_cumsum, gs_model.py:716-722, without the flips)."""
+    _forward_indexed("gcp_cumsum_reverse_indexed", x, sorted_key, index, out)
 
 
 def _forward_carry(fn_name, x, inv, carry, y):

@@ -292,6 +292,65 @@ def stable_sort_keys(keys, key_bits=None):
     return out_k, out_i
 
 
+def rects_key_bits(rects):
+    """Bits of the largest pixel key y*10000 + x of a rect list (one device->host read of two ints; raises on negative
+    coordinates).  Callers that know the image size pass key_bits = (height*10000 + width).bit_length() instead."""
+    r = _dev_tensor(rects, "rects", torch.int32, (2,))
+    out = torch.empty(2, dtype=torch.int32, device=r.device)
+    with torch.cuda.device(r.device):
+        _lib.check(_lib.load().gcp_rects_key_range(r.data_ptr(), r.size(0), out.data_ptr(), _stream(r.device)), "gcp_rects_key_range")
+    mx, mn = out.tolist()
+    _require(r.size(0) == 0 or mn >= 0, "rects: negative coordinates are not supported")
+    return max(1, int(mx).bit_length())
+
+
+def sort_rects(rects, key_bits=None):
+    """Stable sort of the reference's pixel keys straight from its rect list (gs_model.py:538-541, :546-547): returns
+    (sorted_key int32[n], index int32[n]) = torch.sort(rects[:,1]*10000 + rects[:,0], stable=True) without ever writing
+    the unsorted key array.  `key_bits`: bits of the largest key ((H*10000+W).bit_length()); None = one read-back."""
+    r = _dev_tensor(rects, "rects", torch.int32, (2,))
+    n = r.size(0)
+    dev = r.device
+    out_k = torch.empty(n, dtype=torch.int32, device=dev)
+    out_i = torch.empty(n, dtype=torch.int32, device=dev)
+    if n == 0:
+        return out_k, out_i
+    if key_bits is None:
+        key_bits = rects_key_bits(r)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.gcp_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_sort_rects(r.data_ptr(), n, int(key_bits), out_k.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      _stream(dev)), "gcp_sort_rects")
+    return out_k, out_i
+
+
+def compact_finish(inclusive, self_values, mode, begin=0, end=None):
+    """The tail of _create_alpha_brend (gs_model.py:557-564) on the un-sorted inclusive values, rows [begin, end):
+    -> (values f32[n_kept] = inclusive / self (mode 0) or inclusive - self (mode 1) of the rows whose inclusive value is
+    not 0, keep bool[end - begin]).  One device->host read (the kept count sizes the returned tensor, as the reference's
+    boolean-mask indexing does)."""
+    inc = _dev_tensor(inclusive, "inclusive", torch.float32)
+    sv = _dev_tensor(self_values, "self_values", torch.float32)
+    _require(inc.dim() == 1 and sv.shape == inc.shape, "inclusive / self_values: expected two 1-D tensors of one length")
+    end = inc.numel() if end is None else int(end)
+    begin = int(begin)
+    _require(0 <= begin <= end <= inc.numel(), "compact_finish: bad row range")
+    dev = inc.device
+    n = end - begin
+    values = torch.empty(n, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    if n == 0:
+        return values, keep.view(torch.bool)
+    lib = _lib.load()
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = torch.empty(lib.gcp_compact_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_compact_finish(inc.data_ptr(), sv.data_ptr(), begin, end, int(mode), values.data_ptr(), keep.data_ptr(),
+                                          count.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gcp_compact_finish")
+    return values[: int(count.item())], keep.view(torch.bool)
+
+
 def gather_f32(src, index):
     """src[index] for an int32 permutation (gs_model.py:548)."""
     src = _dev_tensor(src, "src", torch.float32)

@@ -1,0 +1,192 @@
+"""Rows a5 / a6 (the reference's only live callers of the scans): `_create_alpha_brend` (gs_model.py:544-566) and
+`grad_cumsum` (:716-722) on the HIP library — key-from-rects stable sort, indexed scan, stream compaction — against the
+literal CPU restatement oracle/wrappers.py (itself pinned to the reference Function's outputs in tests/test_oracle.py
+and tests/test_golden_gpu.py), at BASELINE config 2 scene size and on the edge cases of every stage."""
+import pytest
+import torch
+
+from tests.util import TOL, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _rects_of(sc, device):
+    from simplegaussiansplat_tk71_amd import raster
+
+    return raster.expand_rects(sc["start"].to(device), sc["end"].to(device), sc["width"], sc["height"], with_gaussian=True)
+
+
+def _parity(got, want, scale, what):
+    err = (got.double().cpu() - want.double()).abs()
+    bound = TOL * (1.0 + scale.double())
+    assert bool((err <= bound).all()), f"{what}: max err {err.max().item():.3g}"
+
+
+@pytest.mark.parametrize("with_bits", [True, False])
+def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, with_bits):
+    """BASELINE config 2 (1920x1080, 100k Gaussians, 1.65e7 pairs): masks and sort results bit-exact, values within
+    1e-5 of the sequential CPU statement."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import raster, synthetic
+
+    sc = synthetic.make_scene_config("cfg2", seed=3, device=device)
+    rects, owner = raster.expand_rects(sc["start"], sc["end"], sc["width"], sc["height"], with_gaussian=True)
+    m = rects.size(0)
+    assert 1.4e7 < m < 1.9e7
+    g = torch.Generator(device=device).manual_seed(9)
+    anti = 1.0 - sc["opacity"].reshape(-1)[owner.long()] * torch.rand(m, device=device, generator=g)
+    anti[torch.randint(0, m, (m // 50,), device=device, generator=g)] = 0.0  # opaque pairs: everything behind them is dropped
+    grad = torch.randn(m, device=device, generator=g)
+    grad[torch.randint(0, m, (m // 7,), device=device, generator=g)] = 0.0
+    bits = ck.pixel_key_bits(sc["width"], sc["height"]) if with_bits else None
+
+    sk, idx = raster.sort_rects(rects, bits)
+    rc, ac, gc_ = rects.cpu(), anti.cpu(), grad.cpu()
+    for flag in ("cumprod", "cumsum"):
+        vals, mask = ck.create_alpha_brend(rects, anti, flag, key_bits=bits)
+        w_vals, w_mask, w_sorted, w_index = ow.create_alpha_brend(rc, ac, flag)
+        assert torch.equal(sk.cpu(), w_sorted.to(torch.int32)) and torch.equal(idx.cpu().long(), w_index)
+        assert torch.equal(mask.cpu(), w_mask), flag
+        assert vals.numel() == int(w_mask.sum())
+        # values in [0, 1] (products) or sums of a few dozen values in [0, 1]: |err| <= 1e-5 * (1 + |want|)
+        _parity(vals, w_vals, w_vals.abs(), flag)
+    assert int((~w_mask).sum()) > 1000  # the compaction had something to drop
+    vals, mask = ck.grad_cumsum(rects, grad, key_bits=bits)
+    w_vals, w_mask_flipped = ow.grad_cumsum(rc, gc_)
+    assert torch.equal(mask.cpu(), w_mask_flipped.flip(0))  # ours in ORIGINAL order
+    _parity(vals, w_vals, 4.0 + w_vals.abs(), "grad_cumsum")  # suffix sums of ~8 N(0,1) terms per pixel
+
+
+@pytest.mark.parametrize("n_gauss,w,h,mh,seed", [(1, 8, 8, 2, 1), (40, 33, 17, 4, 2), (400, 100, 70, 9, 3), (3000, 300, 200, 12, 4)])
+@pytest.mark.parametrize("cut", [None, 0, 5, 1001])
+def test_wrappers_small_scenes_and_cutting_number(device, n_gauss, w, h, mh, seed, cut):
+    """The carry rows of the reference's chunked calls (gs_model.py:557-559 drops the first `cutting_number` rows; for
+    grad_cumsum they are the LAST rows of the un-flipped arrays)."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+
+    sc = make_scene(n_gauss, w, h, mh, seed)
+    rects, _ = _rects_of(sc, device)
+    m = rects.size(0)
+    if cut and cut >= m:
+        pytest.skip("cut larger than the pair list")
+    g = torch.Generator().manual_seed(seed)
+    anti = (1.0 - 0.95 * torch.rand(m, generator=g))
+    anti[::13] = 0.0
+    grad = torch.randn(m, generator=g)
+    grad[::5] = 0.0
+    for flag in ("cumprod", "cumsum"):
+        vals, mask = ck.create_alpha_brend(rects, anti.to(device), flag, cut)
+        w_vals, w_mask, _, _ = ow.create_alpha_brend(rects.cpu(), anti, flag, cut)
+        assert torch.equal(mask.cpu(), w_mask)
+        torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4 if flag == "cumsum" else TOL, rtol=TOL)
+    vals, mask = ck.grad_cumsum(rects, grad.to(device), cut)
+    w_vals, w_mask_flipped = ow.grad_cumsum(rects.cpu(), grad, cut)
+    assert torch.equal(mask.cpu(), w_mask_flipped.flip(0))
+    torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4, rtol=TOL)
+
+
+@pytest.mark.parametrize("n,wmax,hmax", [(1, 3, 3), (63, 7, 5), (4096, 1919, 1079), (4097, 50, 50), (100003, 1919, 1079),
+                                        (3_000_017, 3839, 2159), (50_000, 0, 0), (1_000_000, 9999, 200_000)])
+def test_sort_rects_equals_torch_stable_sort_of_the_keys(device, n, wmax, hmax):
+    """gcp_sort_rects: same sorted keys AND the same permutation as torch.sort(y*10000+x, stable=True), with the key
+    width given and with the key range read back."""
+    import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator().manual_seed(n)
+    rects = torch.stack([torch.randint(0, wmax + 1, (n,), generator=g), torch.randint(0, hmax + 1, (n,), generator=g)], 1).to(torch.int32)
+    key = rects[:, 1] * 10000 + rects[:, 0]
+    want_k, want_i = torch.sort(key, stable=True)
+    for bits in (None, ck.pixel_key_bits(wmax, hmax), 31):
+        got_k, got_i = raster.sort_rects(rects.to(device), bits)
+        assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_i.cpu().long(), want_i), bits
+    assert raster.rects_key_bits(rects.to(device)) == max(1, int(key.max()).bit_length())
+
+
+def test_sort_rects_refuses_negative_coordinates_when_it_has_to_look(device):
+    from simplegaussiansplat_tk71_amd import raster
+
+    rects = torch.tensor([[3, 4], [-1, 2]], dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="negative"):
+        raster.sort_rects(rects)
+    e = torch.zeros(0, 2, dtype=torch.int32, device=device)
+    k, i = raster.sort_rects(e)
+    assert k.numel() == 0 and i.numel() == 0
+
+
+@pytest.mark.parametrize("dist", ["poisson8", "geo80", "runs9000", "one_run", "mixed"])
+@pytest.mark.parametrize("n", [1, 5, 4095, 4097, 100003, 1_200_011])
+def test_indexed_scans_equal_gather_scan_scatter(device, n, dist):
+    """out[index[i]] = scan of x[index[i]]: bit-identical to gather -> plain scan -> scatter (same kernel, same
+    association), for all three indexed modes, aligned and unaligned bases, long groups through the descriptor tree."""
+    import grouped_cumprod as gc
+    from tests.util import make_keys, make_values
+
+    key = make_keys(n, dist, seed=n % 97).to(device)
+    g = torch.Generator().manual_seed(n)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(device)
+    x = make_values(n, 3, "near1" if dist in ("one_run", "runs9000") else "alpha").to(device)
+    xs = make_values(n, 4, "normal").to(device)
+    for off in (0, 1):
+        pd, kd = perm, key
+        if off:  # contiguous views off the 16-byte boundary: dword path
+            pd = torch.cat([perm.new_zeros(1), perm])[1:]
+            kd = torch.cat([key.new_zeros(1), key])[1:]
+            assert pd.data_ptr() % 16 != 0
+        for fn_i, fn, src in ((gc.grouped_cumprod_forward_indexed, gc.grouped_cumprod_forward, x),
+                              (gc.grouped_cumsum_forward_indexed, gc.grouped_cumsum_forward, xs),
+                              (gc.grouped_cumsum_reverse_indexed, gc.grouped_cumsum_reverse, xs)):
+            got = torch.full((n,), float("nan"), device=device)
+            fn_i(src, kd, pd, got)
+            sorted_x = src[perm.long()].contiguous()
+            y = torch.empty(n, device=device)
+            fn(sorted_x, key, y)
+            want = torch.empty(n, device=device)
+            want[perm.long()] = y
+            assert torch.equal(got, want), (fn_i.__name__, off)
+
+
+def test_indexed_scan_argument_checks(device):
+    import grouped_cumprod as gc
+
+    n = 100
+    x = torch.rand(n, device=device)
+    k = torch.zeros(n, dtype=torch.int32, device=device)
+    i = torch.arange(n, dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="overlaps"):
+        gc.grouped_cumprod_forward_indexed(x, k, i, x)
+    with pytest.raises(RuntimeError, match="Int"):
+        gc.grouped_cumprod_forward_indexed(x, k, i.long(), torch.empty_like(x))
+    with pytest.raises(RuntimeError, match="elements"):
+        gc.grouped_cumprod_forward_indexed(x, k, i[:50], torch.empty_like(x))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gc.grouped_cumprod_forward_indexed(x.cpu(), k.cpu(), i.cpu(), torch.empty(n))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4096, 4097, 100_003, 2_000_001])
+@pytest.mark.parametrize("zero_every", [0, 1, 2, 7, 1000])
+def test_compact_finish_equals_the_torch_statement(device, n, zero_every):
+    """keep = inclusive != 0; values = (inclusive / self | inclusive - self)[keep] (gs_model.py:557-564), on aligned and
+    unaligned row ranges; NaN counts as non-zero, as in torch."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator(device=device).manual_seed(n + zero_every)
+    inc = torch.randn(n, device=device, generator=g)
+    if zero_every == 1:
+        inc.zero_()
+    elif zero_every:
+        inc[::zero_every] = 0.0
+    if n > 10:
+        inc[7] = float("nan")
+        inc[9] = -0.0  # equals 0: dropped
+    sv = torch.rand(n, device=device, generator=g) + 0.5
+    for begin, end in ((0, n), (min(1, n), n), (0, max(0, n - 3)), (min(5, n), max(min(5, n), n - 2))):
+        for mode in (0, 1):
+            vals, keep = raster.compact_finish(inc, sv, mode, begin, end)
+            a, b = inc[begin:end], sv[begin:end]
+            want_keep = a != 0
+            want = (a / b if mode == 0 else a - b)[want_keep]
+            assert torch.equal(keep, want_keep)
+            torch.testing.assert_close(vals, want, rtol=2e-7, atol=0.0, equal_nan=True)  # (an ulp: the division's rounding mode)

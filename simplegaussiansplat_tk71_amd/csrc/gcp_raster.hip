@@ -327,6 +327,194 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same pass for M-sized key arrays (gcp_sort_pairs_u32 / gcp_sort_rects), organised for throughput.  The two kernels
+// above spend their time waiting: a block lives for one 4096-key chunk, four of them fit a CU, and each goes load ->
+// barrier -> count -> barrier -> rank -> barrier -> copy-out with nothing in flight behind it (measured: 0.9 ms per
+// pass at 1.65e8 keys of which 0.1 ms is the scattered stores; the histogram pass another 0.33 ms).  Here one block
+// owns a SUPER-CHUNK of up to kSortSub consecutive chunks:
+//   * histogram: one column per super-chunk (8x fewer scattered counter writes, a 5 MB table that one tiny scan
+//     handles), 16-byte loads, and counts aggregated over runs of equal digits in neighbouring lanes before they reach
+//     the LDS atomic (pixel keys arrive partially ordered: without this the upper digits serialise 64-way);
+//   * scatter: the digit offsets of the block's first chunk come from the scanned table, the following chunks
+//     continue from them (+= the chunk's own counts); 8 waves per block (8 instead of 16 dependent steps per wave and
+//     chunk, 24 instead of 16 waves per CU), every key ranked ONCE (the counting phase keeps the ranks), and the
+//     staging writes made independent of each other.
+// Same result as the chunk-at-a-time kernels bit for bit (integer arithmetic only, no atomic decides a slot).
+// ------------------------------------------------------------------------------------------
+#ifndef GCP_SORT_BIG
+#define GCP_SORT_BIG 4096  // (8192 with 16 waves and one block per CU: passes 0 / 1 no faster, measured)
+#endif
+constexpr int kBigChunk = GCP_SORT_BIG;  // keys staged through LDS at a time by the M-sized sort
+constexpr int kSortSub = 8;  // chunks per super-chunk at most
+
+// digit counts of one wave's 64 keys into `h`: lanes with the same digit as their left neighbour are counted by the
+// leftmost lane of the run (one LDS atomic per run).  d >= 256 marks a lane without a key.
+__device__ __forceinline__ void count_runs(int* h, unsigned d, int lane) {
+  const unsigned dl = (unsigned)dpp_i<0x138, 0xf>((int)0xffffffffu, (int)d);  // wave_shr:1, lane 0 sees "no key"
+  const bool head = (lane == 0) || (d != dl);
+  const unsigned long long heads = __ballot(head);
+  if (head && d < 256u) {
+    const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+    const int len = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+    atomicAdd(&h[d], len);
+  }
+}
+
+template <bool RECTS>
+__global__ __launch_bounds__(256) void k_sort_hist2(const unsigned* key, i64 n, int shift, int* hist, int nsuper, int sub, int xcd_remap,
+                                                    int vec /*the source is 16-byte aligned*/) {
+  __shared__ int h[256];
+  const i64 super = sort_chunk(blockIdx.x, nsuper, xcd_remap);
+  if (super < 0) return;
+  const int lane = threadIdx.x & 63;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const i64 base = super * (i64)sub * kBigChunk;
+  const i64 end = min(n, base + (i64)sub * kBigChunk);
+  // 4 consecutive keys per lane per step; the order inside the super-chunk does not matter for a histogram
+  for (i64 p0 = base; p0 < end; p0 += 1024) {  // block-uniform trip count: count_runs needs all 64 lanes of every wave
+    const i64 p = p0 + (i64)threadIdx.x * 4;
+    unsigned k4[4];
+    if (vec && p + 3 < end) {
+      if (RECTS) {
+        const int4 a = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(key) + p);
+        const int4 b = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(key) + p + 2);
+        k4[0] = (unsigned)(a.y * 10000 + a.x); k4[1] = (unsigned)(a.w * 10000 + a.z);
+        k4[2] = (unsigned)(b.y * 10000 + b.x); k4[3] = (unsigned)(b.w * 10000 + b.z);
+      } else {
+        const uint4 a = *reinterpret_cast<const uint4*>(key + p);
+        k4[0] = a.x; k4[1] = a.y; k4[2] = a.z; k4[3] = a.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k4[j] = (k4[j] >> shift) & 255u;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k4[j] = (p + j < end) ? ((load_key<RECTS>(key, p + j) >> shift) & 255u) : 256u;
+    }
+    // element j of every lane: neighbouring lanes hold keys 4 apart — still mostly equal upper digits
+#pragma unroll
+    for (int j = 0; j < 4; ++j) count_runs(h, k4[j], lane);
+  }
+  __syncthreads();
+  hist[(i64)threadIdx.x * nsuper + super] = h[threadIdx.x];
+}
+
+// Peers of every lane = the lanes of the wave that hold the same 8-bit digit, as a 64-bit mask in two dwords.  Per digit
+// bit: one ballot, and the lanes that DIFFER in that bit are OR-ed into a mismatch mask (ballot ^ own bit replicated) —
+// 5 VALU per bit instead of the 8 of a select-and-AND formulation; this loop is what the scatter kernel's time is made
+// of (it issues 2/3 of its vector instructions).
+__device__ __forceinline__ void digit_peers(unsigned d, unsigned long long valid, unsigned& lo, unsigned& hi) {
+  unsigned acc_lo = 0u, acc_hi = 0u;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int sb = ((int)(d << (31 - b))) >> 31;  // 0 / -1: this lane's bit b, replicated
+    const unsigned long long m = __ballot(sb != 0);
+    acc_lo |= (unsigned)m ^ (unsigned)sb;
+    acc_hi |= (unsigned)(m >> 32) ^ (unsigned)sb;
+  }
+  lo = (unsigned)valid & ~acc_lo;
+  hi = (unsigned)(valid >> 32) & ~acc_hi;
+}
+
+constexpr int kSortWaves = kBigChunk / 512;  // 8 steps of 64 keys per wave and chunk
+
+template <bool FIRST, bool RECTS>
+__global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigned* key, const unsigned* val, unsigned* key_out,
+                                                                    unsigned* val_out, i64 n, int shift, const int* hist_excl,
+                                                                    int nsuper, int sub, int xcd_remap) {
+  const i64 super = sort_chunk(blockIdx.x, nsuper, xcd_remap);
+  if (super < 0) return;
+  __shared__ unsigned s_key[kBigChunk];
+  __shared__ unsigned s_val[kBigChunk];
+  __shared__ int off[kSortWaves][256];  // (A) per-wave digit counts -> (B) first LDS slot of (wave, digit)
+  __shared__ int gdelta[256];           // global slot = LDS slot + gdelta[digit]
+  __shared__ int gbase[256];            // first global slot of the CURRENT chunk's keys of every digit
+  __shared__ int s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int kThreadsS = 64 * kSortWaves;
+  constexpr int kWaveKeys = kBigChunk / kSortWaves;  // 512
+  constexpr int kSteps = kWaveKeys / 64;              // 8
+  const i64 sbase = super * (i64)sub * kBigChunk;
+  const int nsub = (int)min((i64)sub, (n - sbase + kBigChunk - 1) / kBigChunk);
+  if (tid < 256) gbase[tid] = hist_excl[(i64)tid * nsuper + super];
+  for (int c = 0; c < nsub; ++c) {
+    const i64 bbase = sbase + (i64)c * kBigChunk;
+    const i64 wbase = bbase + (i64)w * kWaveKeys;
+    unsigned k[kSteps], v[kSteps];
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const i64 i = wbase + st * 64 + lane;
+      const bool valid = i < n;
+      k[st] = valid ? load_key<RECTS>(key, i) : 0u;  // (non-temporal loads here: no difference, measured)
+      v[st] = FIRST ? (unsigned)i : (valid ? val[i] : 0u);
+    }
+    for (int d = lane; d < 256; d += 64) off[w][d] = 0;
+    __syncthreads();  // (also: the previous chunk's copy-out has read s_key / s_val / gdelta)
+    // (A) ranks.  Per step of 64 keys: the peers of every lane; its rank among them (lanes below it); the leader (lowest
+    // peer) adds the peer count to the wave's counter of that digit and gets back how many keys of the digit the wave's
+    // EARLIER steps held — one lane per address and instruction, the steps of a wave in program order, so the returned
+    // value does not depend on any arbitration — and hands it to its peers.  slot[st] = position among the wave's keys of
+    // this digit: nothing is left to do in (C) but to add the digit's base.
+    int slot[kSteps];
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {
+      const bool valid = wbase + st * 64 + lane < n;
+      const unsigned d = (k[st] >> shift) & 255u;
+      unsigned plo, phi;
+      digit_peers(d, __ballot(valid), plo, phi);
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+      const int cnt = __builtin_popcount(plo) + __builtin_popcount(phi);
+      int before = 0;
+      if (valid && rank == 0) before = atomicAdd(&off[w][d], cnt);
+      const int leader = plo ? __builtin_ctz(plo) : (32 + __builtin_ctz(phi | 0x80000000u));
+      before = __builtin_amdgcn_ds_bpermute(leader << 2, before);
+      slot[st] = before + rank;
+    }
+    __syncthreads();
+    {  // (B) thread d < 256: digit total -> block-wide exclusive prefix over digits -> per-wave LDS bases; global bases move on
+      int cw[kSortWaves], sum = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < kSortWaves; ++j) { cw[j] = off[j][tid]; sum += cw[j]; }
+      }
+      const int inc = wave_incl_scan_i(sum);
+      if (lane == 63 && w < 4) s_w[w] = inc;
+      __syncthreads();
+      if (tid < 256) {
+        int run = inc - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < w) run += s_w[j];
+        const int gb = gbase[tid];
+        gdelta[tid] = gb - run;
+        gbase[tid] = gb + sum;
+#pragma unroll
+        for (int j = 0; j < kSortWaves; ++j) { off[j][tid] = run; run += cw[j]; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < kSteps; ++st) {  // (C) staged into LDS in digit order: independent reads and writes
+      if (wbase + st * 64 + lane < n) {
+        const int pos = off[w][(k[st] >> shift) & 255u] + slot[st];
+        s_key[pos] = k[st];
+        s_val[pos] = v[st];
+      }
+    }
+    __syncthreads();
+    const int nvalid = (int)((n - bbase < kBigChunk) ? (n - bbase) : kBigChunk);
+    for (int i = tid; i < nvalid; i += kThreadsS) {  // (D) coalesced copy-out: consecutive lanes, consecutive slots
+      const unsigned kk = s_key[i];
+      const i64 g = (i64)i + gdelta[(kk >> shift) & 255u];
+      if ((unsigned long long)g < (unsigned long long)n) {  // always true; keeps a broken histogram from becoming a wild store
+        key_out[g] = kk;
+        val_out[g] = s_val[i];
+      }
+    }
+  }
+}
+
 // tile_start[t] = first sorted entry whose tile id is >= t, for t in [0, n_tiles]
 __global__ void k_tile_bounds(const unsigned* key, i64 K, int n_tiles, int* tile_start, const int* n_dev) {
   if (n_dev) K = min(K, (i64)*n_dev);
@@ -1183,8 +1371,12 @@ static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key
   if (!keys_in || !keys_out || !index_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_sort_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
   static const int xcd_remap = [] { const char* e = getenv("GCP_SORT_XCD"); return (e && *e) ? atoi(e) : 1; }();
-  const i64 nblk = (n + kSortChunk - 1) / kSortChunk;
-  const dim3 grid(sort_grid(nblk, xcd_remap)), block(256);
+  const i64 nblk = (n + kBigChunk - 1) / kBigChunk;
+  // chunks per block: as many as kSortSub, but keep a few thousand blocks for the 1024 block slots of the chip
+  int sub = (int)(nblk / 2048);
+  sub = sub < 1 ? 1 : (sub > kSortSub ? kSortSub : sub);
+  const i64 nsuper = (nblk + sub - 1) / sub;
+  const dim3 grid(sort_grid(nsuper, xcd_remap)), block(256);
   char* p = (char*)ws;
   unsigned* keyY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
   unsigned* valY = (unsigned*)p; p += align256((size_t)n * sizeof(unsigned));
@@ -1196,26 +1388,28 @@ static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key
   const int passes = (key_bits + 7) / 8;
   const unsigned* ks = keys_in;
   const unsigned* vs = nullptr;
-  const int* no_count = nullptr;
   for (int pass = 0; pass < passes; ++pass) {
     const bool to_x = ((passes - 1 - pass) & 1) == 0;  // the last pass lands in the caller's buffers
     unsigned* kd = to_x ? keyX : keyY;
     unsigned* vd = to_x ? valX : valY;
     const int shift = 8 * pass;
-    if (pass == 0 && rects) hipLaunchKernelGGL((k_sort_hist<true>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nblk, no_count, xcd_remap);
-    else hipLaunchKernelGGL((k_sort_hist<false>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nblk, no_count, xcd_remap);
+    const bool src_rects = pass == 0 && rects;
+    const int vec = (((uintptr_t)ks & 15u) == 0) ? 1 : 0;  // (the ping-pong buffers always are; a caller's view may not be)
+    if (src_rects) hipLaunchKernelGGL((k_sort_hist2<true>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nsuper, sub, xcd_remap, vec);
+    else hipLaunchKernelGGL((k_sort_hist2<false>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nsuper, sub, xcd_remap, vec);
     GCP_HIP(hipGetLastError());
-    const int st = launch_excl_scan(hist, hist_ex, 256 * nblk, sws, stream);
+    const int st = launch_excl_scan(hist, hist_ex, 256 * nsuper, sws, stream);
     if (st != GCP_OK) return st;
-    if (pass == 0 && rects)
-      hipLaunchKernelGGL((k_sort_scatter<true, true>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
-                         (int)nblk, no_count, xcd_remap);
+    const dim3 sblock(64 * kSortWaves);
+    if (src_rects)
+      hipLaunchKernelGGL((k_sort_scatter2<true, true>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nsuper, sub, xcd_remap);
     else if (pass == 0)
-      hipLaunchKernelGGL((k_sort_scatter<true, false>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
-                         (int)nblk, no_count, xcd_remap);
+      hipLaunchKernelGGL((k_sort_scatter2<true, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nsuper, sub, xcd_remap);
     else
-      hipLaunchKernelGGL((k_sort_scatter<false, false>), grid, block, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
-                         (int)nblk, no_count, xcd_remap);
+      hipLaunchKernelGGL((k_sort_scatter2<false, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+                         (int)nsuper, sub, xcd_remap);
     GCP_HIP(hipGetLastError());
     ks = kd;
     vs = vd;

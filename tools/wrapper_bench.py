@@ -45,41 +45,47 @@ def scene_inputs(cfg, dev, seed=0):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    stages = "--stages" in sys.argv
+    argv = sys.argv[1:]
     iters = 5
-    if "--iters" in sys.argv:
-        iters = int(sys.argv[sys.argv.index("--iters") + 1])
+    if "--iters" in argv:
+        i = argv.index("--iters")
+        iters = int(argv[i + 1])
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
+    stages = "--stages" in argv
     dev = torch.device("cuda", 0)
     for cfg in (args or ["cfg2", "cfg3"]):
         sc, rects, anti, grad = scene_inputs(cfg, dev)
         m = rects.size(0)
         w, h = sc["width"], sc["height"]
         out = {"workload": cfg, "pairs": m, "gaussians": int(sc["start"].size(0))}
-        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)
-        out["create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum"), iters)
-        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad), iters)
+        bits = ck.pixel_key_bits(w, h)
+        out["key_bits"] = bits
+        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits), iters)
+        out["create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", key_bits=bits), iters)
+        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, key_bits=bits), iters)
+        out["create_alpha_brend_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)
         out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
         out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
-        if hasattr(ck, "wrapper_stage_times"):
-            out["stages"] = ck.wrapper_stage_times(rects, anti, timeit, iters)
-        elif stages:
-            key = ck.unique(rects).contiguous()
-            bits = int(key.max().item()).bit_length()
-            st = {"unique_ms": timeit(lambda: ck.unique(rects).contiguous(), iters),
-                  "sort_ms": timeit(lambda: raster.stable_sort_keys(key, key_bits=bits), iters),
-                  "sort_with_readback_ms": timeit(lambda: raster.stable_sort_keys(key), iters)}
-            sk, idx = raster.stable_sort_keys(key, key_bits=bits)
-            st["gather_ms"] = timeit(lambda: raster.gather_f32(anti, idx), iters)
-            sx = raster.gather_f32(anti, idx)
-            y = torch.empty_like(sx)
+        if stages:
             import grouped_cumprod as gc
-            st["scan_ms"] = timeit(lambda: gc.grouped_cumprod_forward(sx, sk, y), iters)
-            st["unsort_finish_ms"] = timeit(lambda: raster.unsort_finish(y, sx, idx, 0), iters)
-            full, keep = raster.unsort_finish(y, sx, idx, 0)
-            st["compaction_ms"] = timeit(lambda: full[keep], iters)
-            st["dropped_pairs"] = int(m - keep.sum().item())
+
+            st = {"sort_rects_ms": timeit(lambda: raster.sort_rects(rects, bits), iters)}
+            sk, idx = raster.sort_rects(rects, bits)
+            incl = torch.empty_like(anti)
+            st["indexed_scan_ms"] = timeit(lambda: gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl), iters)
+            st["indexed_reverse_scan_ms"] = timeit(lambda: gc.grouped_cumsum_reverse_indexed(grad, sk, idx, incl), iters)
+            gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl)
+            st["compact_finish_ms"] = timeit(lambda: raster.compact_finish(incl, anti, 0), iters)
+            vals, keep = raster.compact_finish(incl, anti, 0)
+            st["dropped_pairs"] = int(m - vals.numel())
+            st["key_range_ms"] = timeit(lambda: raster.rects_key_bits(rects), iters)
+            y = torch.empty_like(anti)
+            st["plain_scan_same_size_ms"] = timeit(lambda: gc.grouped_cumprod_forward(anti, sk, y), iters)
+            del sk, idx, incl, y, vals, keep
+            key = ck.unique(rects).contiguous()
             st["torch_sort_stable_ms"] = timeit(lambda: torch.sort(key, stable=True), 3, 1)
+            del key
             out["stages"] = st
         print(json.dumps(out), flush=True)
         del rects, anti, grad, sc

@@ -293,6 +293,18 @@ int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, vo
  * count_dev[0] (device int32) receives the number of kept elements.  Stable stream compaction in two launches (per-tile
  * counts, then ranks from one exclusive scan of them): no atomics, deterministic.  values needs room for end - begin
  * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 17 B / element. */
+/* Rows a5 / a6 for callers that still hold the boxes their rect list was expanded from (gs_model.py:601 -> :607): key,
+ * stable sort, gather, grouped scan and un-sort of _create_alpha_brend (gs_model.py:546-555) as ONE walk of the tile lists of
+ * gcp_bin_tiles*.  x / inclusive: f32[M] in the reference's Gaussian-major rect order (uitility.py:336-366); box_off:
+ * int32[n_gauss + 1] exclusive prefix sums of the clamped box sizes (gcp_box_sizes + gcp_exclusive_scan_i32).
+ *   inclusive[pair] = product (mode 0) / sum (mode 1) of x over the pairs of the same pixel up to and including this one
+ *   in depth order; mode 2: sum from this one to the deepest (grad_cumsum's flipped scan, gs_model.py:716-722).
+ * Every pixel is scanned sequentially in depth order (the association of the CPU statement).  8 B / pair.  Feed the result
+ * to gcp_compact_finish. */
+int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                         const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
+                         float* inclusive, int32_t mode, void* stream);
+
 size_t gcp_compact_workspace_bytes(int64_t n);
 int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
                        uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);

@@ -938,6 +938,91 @@ __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __r
   if (!FILL && in_img) pixel_count[(i64)py * (a.W + 1) + px] = n;
 }
 
+// ------------------------------------------------------------------------------------------
+// Rows a5 / a6 for a caller that still holds the BOXES its rect list was expanded from (gs_model.py:601 `_create_rects`
+// feeds :607): the sort -> gather -> scan -> un-sort of _create_alpha_brend (gs_model.py:546-555) collapses into one walk
+// of the depth-ordered tile lists.  One block per 16x16 tile, one pixel per lane; every lane walks the tile's list and,
+// for the entries whose box holds its pixel, reads the pair's value at its Gaussian-major position
+//   box_off[g] + (py - y0) * width_g + (px - x0)            (uitility.py:336-366)
+// folds it into its running product / sum and writes the INCLUSIVE value back to the same position — exactly
+// `output[torch.argsort(index)]` of gs_model.py:555, with every pixel scanned strictly front to back (the CPU path's own
+// association; MODE 2: back to front = grad_cumsum's flipped scan, gs_model.py:716-722).  No M-sized sort, no M-sized
+// index array: 8 B per pair.  Lanes of one pixel row read and write consecutive addresses (64 B per box row and tile).
+// ------------------------------------------------------------------------------------------
+constexpr int kWalkStage = 64;  // list entries staged per round: one hit word per wave
+template <int MODE>  // 0 cumprod, 1 cumsum, 2 reverse cumsum
+__global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
+                                                          const float* __restrict__ x, float* __restrict__ out) {
+  __shared__ int4 s_box[kWalkStage];   // x0, y0, x1, y1 (clamped to the image)
+  __shared__ int s_off[kWalkStage];    // first Gaussian-major pair of the entry's Gaussian
+  __shared__ unsigned long long s_hits[4];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = blockIdx.x;
+  const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
+  const int px = tile_x0 + (lane & 15);
+  const int py = tile_y0 + w * 4 + (lane >> 4);
+  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  const int nrounds = (last - first + kWalkStage - 1) / kWalkStage;
+  float acc = (MODE == 0) ? 1.0f : 0.0f;
+  for (int q0 = 0; q0 < nrounds; ++q0) {
+    const int q = (MODE == 2) ? (nrounds - 1 - q0) : q0;
+    const int base = first + q * kWalkStage;
+    const int cnt = min(kWalkStage, last - base);
+    __syncthreads();
+    if (threadIdx.x < kWalkStage) {  // wave 0 stages the round
+      const int j = threadIdx.x;
+      unsigned rm = 0u;
+      if (j < cnt) {
+        const i64 g = a.tile_list[base + j];
+        Box b;
+        load_box(a.start, a.end, g, a.W, a.H, b);
+        s_box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
+        s_off[j] = box_off[g];
+        const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
+        rm = (r1 >= r0) ? ((2u << r1) - (1u << r0)) : 0u;
+      }
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const unsigned long long touched = __ballot(((rm >> (4 * w2)) & 0xfu) != 0u);
+        if (j == 0) s_hits[w2] = touched;
+      }
+    }
+    __syncthreads();
+    unsigned long long hits = uniform64(s_hits[w]);
+    // four listed entries at a time: their loads are issued together, then folded in list order
+    while (hits) {
+      int kk[4];
+      int idx[4];
+      bool in[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        kk[u] = -1;
+        if (hits) {
+          kk[u] = (MODE == 2) ? (63 - __builtin_clzll(hits)) : __builtin_ctzll(hits);
+          hits &= ~(1ull << kk[u]);
+        }
+        in[u] = false;
+        idx[u] = 0;
+        if (kk[u] >= 0) {  // wave-uniform
+          const int4 bx = s_box[kk[u]];
+          in[u] = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
+          idx[u] = s_off[kk[u]] + (py - bx.y) * (bx.z - bx.x + 1) + (px - bx.x);
+        }
+        v[u] = in[u] ? x[idx[u]] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (in[u]) {
+          acc = (MODE == 0) ? acc * v[u] : acc + v[u];
+          out[idx[u]] = acc;
+        }
+      }
+    }
+  }
+}
+
 // Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
 // _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
 // One thread per pair; the owning Gaussian is found by bisection in the box offsets.
@@ -1474,6 +1559,24 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
                               (int*)nullptr, (const int*)off, values, keep, count_dev);
   else hipLaunchKernelGGL((k_compact<false, true>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode,
                           (int*)nullptr, (const int*)off, values, keep, count_dev);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                         const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
+                         float* inclusive, int32_t mode, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BlendArgs a;
+  const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
+  if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !tile_list || !box_off || !x || !inclusive || x == inclusive) return GCP_ERR_INVALID_ARGUMENT;
+  const TileGrid tg = tile_grid(width, height);
+  const dim3 grid((unsigned)(tg.tx * tg.ty)), block(256);
+  if (mode == 0) hipLaunchKernelGGL((k_pairs_scan_boxes<0>), grid, block, 0, stream, a, box_off, x, inclusive);
+  else if (mode == 1) hipLaunchKernelGGL((k_pairs_scan_boxes<1>), grid, block, 0, stream, a, box_off, x, inclusive);
+  else hipLaunchKernelGGL((k_pairs_scan_boxes<2>), grid, block, 0, stream, a, box_off, x, inclusive);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

@@ -255,16 +255,32 @@ def _scan_unsort_compact(sorted_key, index, anti_opacity, flag, cutting_number=N
 create_alpha_blend = create_alpha_brend  # spelling alias
 
 
+def _scan_boxes_compact(startpoint, endpoint, values, image_width, image_height, flag):
+    w, h = int(image_width), int(image_height)
+    values = values.detach().contiguous()
+    bins = _raster.bin_tiles(startpoint, endpoint, w, h)
+    box_off = _raster.box_offsets(startpoint, endpoint, w, h)
+    m = int(box_off[-1].item())
+    if values.numel() != m:
+        raise RuntimeError(f"values: {values.numel()} rows, but the boxes expand to {m} pairs")
+    mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
+    inclusive = _raster.scan_boxes(bins, startpoint, endpoint, box_off, values, mode)
+    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1)
+    return [values_out, keep]
+
+
 def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, image_height, flag="cumprod"):
-    """`create_alpha_brend` for callers that still hold the boxes the rects were expanded from
-    (reference: gs_model.py:601 `_create_rects(startpoint, endpoint)` feeds :607): the sort permutation and
-    the sorted keys come from the tile binning (raster.pixel_lists — bit-identical to `torch.sort(stable)`
-    of the pixel keys) instead of a radix sort over all M pairs.  `anti_opacity` is in the reference's
-    Gaussian-major rect order; returns the same [values, mask]."""
+    """`create_alpha_brend` for callers that still hold the boxes the rects were expanded from (reference: gs_model.py:601
+    `_create_rects(startpoint, endpoint)` feeds :607).  Nothing M-sized is sorted: the Gaussians are binned into 16x16
+    tiles (K ~ 3 entries per Gaussian) and every pixel walks its tile's depth-ordered list, reading and writing each
+    pair at its Gaussian-major position (raster.scan_boxes), then the same stream compaction.  `anti_opacity` is in the
+    reference's Gaussian-major rect order; returns the same [values, mask] as `create_alpha_brend(rects, ...)` — masks
+    identical, values scanned strictly in depth order (the association of the CPU path) instead of the tree order of the
+    flat scan, i.e. equal to it within fp32 round-off."""
+    if flag not in ("cumprod", "cumsum"):
+        raise ValueError(flag)
     with torch.no_grad():
-        bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
-        pl = _raster.pixel_lists(bins, startpoint, endpoint)
-        return _scan_unsort_compact(pl.pair_key, pl.pair_index, anti_opacity, flag)
+        return _scan_boxes_compact(startpoint, endpoint, anti_opacity, image_width, image_height, flag)
 
 
 def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None):
@@ -283,12 +299,10 @@ def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None):
 
 
 def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
-    """`grad_cumsum` (gs_model.py:716-722) with the permutation taken from the tile binning instead of a sort
-    over all M pairs; same [values, mask] as `grad_cumsum(rects, grad)`."""
+    """`grad_cumsum` (gs_model.py:716-722) from the boxes: the tile lists walked back to front; same [values, mask] as
+    `grad_cumsum(rects, grad)` (masks identical, values within fp32 round-off: sequential association)."""
     with torch.no_grad():
-        bins = _raster.bin_tiles(startpoint, endpoint, int(image_width), int(image_height))
-        pl = _raster.pixel_lists(bins, startpoint, endpoint)
-        return _scan_unsort_compact(pl.pair_key, pl.pair_index, grad, "cumsum_reverse")
+        return _scan_boxes_compact(startpoint, endpoint, grad, image_width, image_height, "cumsum_reverse")
 
 
 class custom_autograd_grouped_cumprod(torch.autograd.Function):

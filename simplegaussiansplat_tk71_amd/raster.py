@@ -267,6 +267,39 @@ def expand_rects(startpoint, endpoint, width, height, with_gaussian=False):
     return (rects, owner) if with_gaussian else rects
 
 
+def box_offsets(startpoint, endpoint, width, height):
+    """int32[N+1]: first Gaussian-major pair of every Gaussian in the reference's rect list (uitility.py:336-366), i.e. the
+    exclusive prefix sums of the box sizes clamped to the image; [-1] = M."""
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    n = start.size(0)
+    dev = start.device
+    with torch.cuda.device(dev):
+        bsize = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().gcp_box_sizes(start.data_ptr(), end.data_ptr(), n, int(width), int(height), bsize.data_ptr(), _stream(dev)),
+                   "gcp_box_sizes")
+        return exclusive_scan_i32(bsize[:n])
+
+
+def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
+    """Inclusive per-pixel scan of `values` (f32[M], Gaussian-major rect order) in depth order, result in the same order:
+    mode 0 product, 1 sum, 2 suffix sum — the sort / gather / scan / un-sort of _create_alpha_brend (gs_model.py:546-555)
+    as one walk of the tile lists (gcp_pairs_scan_boxes).  Rows of `values` whose pair lies outside every listed box do
+    not exist by construction (box_off comes from the same boxes)."""
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    x = _dev_tensor(values, "values", torch.float32)
+    off = _dev_tensor(box_off, "box_off", torch.int32)
+    _require(x.dim() == 1, "values: expected a 1-D tensor")
+    _require(off.numel() == bins.n_gauss + 1, "box_off: expected n_gauss + 1 offsets")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().gcp_pairs_scan_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
+                                                    bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
+                                                    out.data_ptr(), int(mode), _stream(x.device)), "gcp_pairs_scan_boxes")
+    return out
+
+
 def stable_sort_keys(keys, key_bits=None):
     """Stable sort of non-negative int32 keys on the HIP library: returns (sorted_keys int32[n], index int32[n]) with
     sorted_keys == keys[index] and equal keys in input order — `torch.sort(keys, stable=True)` as the reference needs

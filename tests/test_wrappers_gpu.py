@@ -51,11 +51,21 @@ def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, with_bi
         assert vals.numel() == int(w_mask.sum())
         # values in [0, 1] (products) or sums of a few dozen values in [0, 1]: |err| <= 1e-5 * (1 + |want|)
         _parity(vals, w_vals, w_vals.abs(), flag)
+        # the same from the boxes (tile-list walk, no M-sized sort): every pixel scanned in the CPU statement's own order
+        b_vals, b_mask = ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, sc["width"], sc["height"], flag)
+        assert torch.equal(b_mask.cpu(), w_mask), flag
+        if flag == "cumprod":
+            assert torch.equal(b_vals.cpu(), w_vals)
+        else:
+            _parity(b_vals, w_vals, w_vals.abs(), flag + " (boxes)")
     assert int((~w_mask).sum()) > 1000  # the compaction had something to drop
     vals, mask = ck.grad_cumsum(rects, grad, key_bits=bits)
     w_vals, w_mask_flipped = ow.grad_cumsum(rc, gc_)
     assert torch.equal(mask.cpu(), w_mask_flipped.flip(0))  # ours in ORIGINAL order
     _parity(vals, w_vals, 4.0 + w_vals.abs(), "grad_cumsum")  # suffix sums of ~8 N(0,1) terms per pixel
+    b_vals, b_mask = ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, sc["width"], sc["height"])
+    assert torch.equal(b_mask.cpu(), w_mask_flipped.flip(0))
+    _parity(b_vals, w_vals, 4.0 + w_vals.abs(), "grad_cumsum (boxes)")
 
 
 @pytest.mark.parametrize("n_gauss,w,h,mh,seed", [(1, 8, 8, 2, 1), (40, 33, 17, 4, 2), (400, 100, 70, 9, 3), (3000, 300, 200, 12, 4)])

@@ -36,10 +36,31 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 BYTES_FWD, BYTES_BWD = 12, 20  # algorithmic bytes per pair
 
 
+def _median_time(fn, reps=5, warmup=1, min_s=0.25):
+    """median of `reps` after `warmup` untimed calls (the first call also takes the page faults of freshly
+    allocated outputs and starts the thread pool: it is never the one reported).  A leg shorter than `min_s` is repeated
+    inside every timed repetition until it lasts that long (a 10 ms call on a shared host is not a measurement);
+    returns seconds per call: (median, min, max)."""
+    t0 = time.perf_counter()
+    for _ in range(warmup):
+        fn()
+    once = max((time.perf_counter() - t0) / max(warmup, 1), 1e-6)
+    inner = max(1, min(64, int(min_s / once + 0.999)))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            fn()
+        ts.append((time.perf_counter() - t0) / inner)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0], ts[-1]
+
+
 def cpu_baseline(p, sample_pairs):
     """Oracle (C port of the reference kernels, oracle/gcp_oracle.c) on the first groups of the pair list, on the host
     cores of this box: OpenMP over pixel groups with up to 16 threads (one GPU's CPU share) = the headline figure,
-    plus the single-thread time on a quarter of the sample and the pure-PyTorch torch.cumprod path."""
+    plus single-thread legs (fwd+bwd, and forward only beside the reference's OWN forward compiled for the host) and the
+    pure-PyTorch torch.cumprod path.  Every leg: one warm-up call, then the median of 5 (min / max kept beside it)."""
     import torch
 
     from oracle import c_oracle as co
@@ -53,52 +74,54 @@ def cpu_baseline(p, sample_pairs):
         g = max(1, min(g, inv_len.numel()))
         return g, int(inv_len[g - 1].item())
 
+    def leg(value_pairs, t, **extra):
+        med, lo, hi = t
+        return {"value": value_pairs / med, "unit": "pairs/s", "median_ms": med * 1e3, "min_ms": lo * 1e3, "max_ms": hi * 1e3,
+                "timing": "1 warm-up + median of 5 (calls shorter than 0.25 s repeated inside each timed repetition)", **extra}
+
     g, s = prefix(sample_pairs)
     x, key, inv, go = (t[:s].cpu().contiguous() for t in (p.x, p.key, p.inv, p.grad_out))
     il = inv_len[:g].contiguous()
     threads = max(1, min(16, os.cpu_count() or 1, co.max_threads()))
-    co.cumprod_forward_mt(x[: il[0]].contiguous(), il[:1].contiguous(), threads)  # load the library, start the thread pool
-    t0 = time.perf_counter()
     y = co.cumprod_forward_mt(x, il, threads)
-    t1 = time.perf_counter()
-    co.cumprod_backward_mt(x, y, go, inv, il, threads)
-    t2 = time.perf_counter()
+    t_f = _median_time(lambda: co.cumprod_forward_mt(x, il, threads), reps=5, warmup=1)
+    t_b = _median_time(lambda: co.cumprod_backward_mt(x, y, go, inv, il, threads), reps=5, warmup=1)
     # single thread, a quarter of the sample
     g1, s1 = prefix(max(1, sample_pairs // 4))
     x1, k1, i1, go1, il1 = x[:s1].contiguous(), key[:s1].contiguous(), inv[:s1].contiguous(), go[:s1].contiguous(), inv_len[:g1].contiguous()
-    t3 = time.perf_counter()
     y1 = co.cumprod_forward(x1, k1)
-    co.cumprod_backward(x1, y1, go1, i1, il1)
-    t4 = time.perf_counter()
+    t_f1 = _median_time(lambda: co.cumprod_forward(x1, k1), reps=5, warmup=1)
+    t_b1 = _median_time(lambda: co.cumprod_backward(x1, y1, go1, i1, il1), reps=5, warmup=1)
     # the "pure-PyTorch torch.cumprod path" of BASELINE.json (per-group torch.cumprod), forward only
-    g8, s8 = prefix(min(8_000_000, s))
-    t5 = time.perf_counter()
-    tp.grouped_cumprod(x[:s8].contiguous(), key[:s8].contiguous())
-    t6 = time.perf_counter()
+    g8, s8 = prefix(min(4_000_000, s))
+    x8, k8 = x[:s8].contiguous(), key[:s8].contiguous()
+    t_tp = _median_time(lambda: tp.grouped_cumprod(x8, k8), reps=5, warmup=1)
     # the reference's OWN forward (grouped_cumprod_forward.cu, unmodified, rocThrust CPP backend: sequential) where the
-    # build container compiled it into oracle/_ref/
+    # build container compiled it into oracle/_ref/; output allocated and touched before the timed calls
     ref_fwd = None
     host = oref.load("grouped_cumprod_ref_host")
     if host is not None:
-        y_ref = torch.empty_like(x1)
-        host.grouped_cumprod_forward(x1[:1024].contiguous(), k1[:1024].contiguous(), y_ref[:1024])
-        t7 = time.perf_counter()
-        host.grouped_cumprod_forward(x1, k1, y_ref)
-        t8 = time.perf_counter()
-        ref_fwd = {"value": s1 / (t8 - t7), "unit": "pairs/s (forward only)", "cores": 1, "kind": "reference",
-                   "sample": f"{s1} pairs, cuda_kernel/grouped_cumprod_forward.cu compiled for the host (oracle/_ref)",
-                   "equals_port": bool(torch.equal(y_ref, y1))}
+        y_ref = torch.zeros_like(x1)
+        t_ref = _median_time(lambda: host.grouped_cumprod_forward(x1, k1, y_ref), reps=5, warmup=1)
+        ref_fwd = leg(s1, t_ref, unit="pairs/s (forward only)", cores=1, kind="reference",
+                      sample=f"{s1} pairs, cuda_kernel/grouped_cumprod_forward.cu compiled for the host (oracle/_ref)",
+                      equals_port=bool(torch.equal(y_ref, y1)))
+    med = t_f[0] + t_b[0]
     return {
-        "value": s / (t2 - t0),
+        "value": s / med,
         "unit": "pairs/s",
         "cores": threads,
         "kind": "port",
+        "timing": "per leg: 1 warm-up + median of 5; value = sample / (median fwd + median bwd)",
         "sample": f"first {g} pixel groups = {s} pairs of the same pair list; oracle/gcp_oracle.c (fp32, every group scanned "
-        f"left to right, literal O(L^2) backward loop of the reference), OpenMP over groups; fwd {1e3*(t1-t0):.1f} ms, "
-        f"bwd {1e3*(t2-t1):.1f} ms; host has {os.cpu_count()} cpus",
-        "single_thread": {"value": s1 / (t4 - t3), "unit": "pairs/s", "cores": 1, "sample": f"{s1} pairs"},
-        "torch_cumprod_path_forward": {"value": s8 / (t6 - t5), "unit": "pairs/s", "threads": torch.get_num_threads(),
-                                       "sample": f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"},
+        f"left to right, literal O(L^2) backward loop of the reference), OpenMP over groups; fwd {1e3*t_f[0]:.1f} ms "
+        f"[{1e3*t_f[1]:.1f}, {1e3*t_f[2]:.1f}], bwd {1e3*t_b[0]:.1f} ms [{1e3*t_b[1]:.1f}, {1e3*t_b[2]:.1f}]; host has {os.cpu_count()} cpus",
+        "single_thread": {"value": s1 / (t_f1[0] + t_b1[0]), "unit": "pairs/s", "cores": 1, "sample": f"{s1} pairs",
+                          "fwd_ms": t_f1[0] * 1e3, "bwd_ms": t_b1[0] * 1e3},
+        "port_forward_single_thread": leg(s1, t_f1, unit="pairs/s (forward only)", cores=1, kind="port",
+                                          sample=f"{s1} pairs, oracle/gcp_oracle.c forward alone — compare with reference_host_forward"),
+        "torch_cumprod_path_forward": leg(s8, t_tp, unit="pairs/s (forward only)", threads=torch.get_num_threads(),
+                                          sample=f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"),
         "reference_host_forward": ref_fwd,
     }
 
@@ -139,6 +162,111 @@ def pmc_function(kernel, workload, counter):
             return json.load(f)[workload][kernel][counter]
     except (OSError, KeyError, ValueError):
         return None
+
+
+# algorithmic bytes per pair of rows a5 / a6, stage by stage
+WRAPPER_BYTES = {
+    "sort": {"pass 0: histogram reads the rects": 8, "pass 0: scatter reads the rects, writes key + index": 16,
+             "passes 1, 2: histogram reads the keys": 8, "passes 1, 2: scatter reads and writes key + index": 32},
+    "indexed scan": {"sorted key": 4, "permutation": 4, "gathered value": 4, "scattered inclusive value": 4},
+    "compaction": {"count pass reads the inclusive values": 4, "write pass reads inclusive + self": 8, "mask": 1, "kept values": 4},
+}
+WRAPPER_BOX_BYTES = {"tile-list walk": {"value read": 4, "inclusive value written": 4},
+                     "compaction": {"count pass": 4, "write pass reads": 8, "mask": 1, "kept values": 4}}
+
+
+def wrapper_level(dev, workload):
+    """Rows a5 / a6 — the reference's only live callers of the scans (`_create_alpha_brend`, gs_model.py:544-566, and
+    `grad_cumsum`, :716-722; call sites :607, :612, :636) — on the pair list of one camera of a scene of the workload's
+    shape: whole-call times (HIP events around the Python call, median of 5 after 2 warm-ups; each call ends with the one
+    device->host read of the kept count that sizes its result, as the reference's boolean-mask indexing does), the stages
+    on their own, and a roofline per route from the byte model above."""
+    import torch
+
+    import cuda_kernel as ck
+    import grouped_cumprod as gc
+    from simplegaussiansplat_tk71_amd import raster, synthetic
+
+    if workload not in synthetic.CONFIGS:
+        return None
+    sc, rects, anti, grad = synthetic.make_scene_pairs(workload, seed=0, device=dev)
+    m = rects.size(0)
+    w, h = sc["width"], sc["height"]
+    bits = ck.pixel_key_bits(w, h)
+
+    def timed(fn, iters=5, warmup=2):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits))
+    t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, key_bits=bits))
+    t_a5_rb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"))
+    t_a5b = timed(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"))
+    t_a6b = timed(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h))
+    # stages of the rects route
+    t_sort = timed(lambda: raster.sort_rects(rects, bits))
+    sk, idx = raster.sort_rects(rects, bits)
+    incl = torch.empty_like(anti)
+    t_scan = timed(lambda: gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl))
+    t_rev = timed(lambda: gc.grouped_cumsum_reverse_indexed(grad, sk, idx, incl))
+    gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl)
+    t_comp = timed(lambda: raster.compact_finish(incl, anti, 0))
+    kept = raster.compact_finish(incl, anti, 0)[0].numel()
+    del sk, idx
+    # stages of the boxes route
+    t_bin = timed(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h))
+    bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
+    boff = raster.box_offsets(sc["start"], sc["end"], w, h)
+    t_walk = timed(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0))
+    b_rects = sum(sum(v.values()) for v in WRAPPER_BYTES.values())
+    b_boxes = sum(sum(v.values()) for v in WRAPPER_BOX_BYTES.values())
+
+    def roof(bytes_per_pair, ms):
+        ach = bytes_per_pair * m / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_pair": bytes_per_pair}
+
+    return {
+        "what": "_create_alpha_brend / grad_cumsum (gs_model.py:544-566, :716-722) on one camera's pair list: Gaussian-major rects, "
+                "stable sort by pixel key, per-pixel scan, un-sort, != 0 compaction, / self | - self",
+        "workload": f"{workload} scene: {w + 1}x{h + 1}, {int(sc['start'].size(0))} Gaussians",
+        "pairs": m,
+        "kept_pairs": kept,
+        "key_bits": bits,
+        "create_alpha_brend_ms": t_a5,
+        "grad_cumsum_ms": t_a6,
+        "create_alpha_brend_key_range_read_back_ms": t_a5_rb,
+        "create_alpha_brend_pairs_per_s": m / (t_a5 * 1e-3),
+        "grad_cumsum_pairs_per_s": m / (t_a6 * 1e-3),
+        "roofline": roof(b_rects, t_a5),
+        "stages_ms": {"sort_rects (3 radix passes of 8 bits)": t_sort, "indexed scan (cumprod)": t_scan, "indexed scan (suffix sum)": t_rev,
+                      "compact_finish": t_comp},
+        "stage_rooflines": {"sort": roof(sum(WRAPPER_BYTES["sort"].values()), t_sort),
+                            "indexed scan": roof(sum(WRAPPER_BYTES["indexed scan"].values()), t_scan),
+                            "compaction": roof(sum(WRAPPER_BYTES["compaction"].values()), t_comp)},
+        "byte_model": WRAPPER_BYTES,
+        "from_boxes": {
+            "what": "the same results from the boxes the rects were expanded from: tile binning + one walk of the tile lists + the same compaction",
+            "create_alpha_brend_boxes_ms": t_a5b,
+            "grad_cumsum_boxes_ms": t_a6b,
+            "pairs_per_s": m / (t_a5b * 1e-3),
+            "stages_ms": {"bin_tiles": t_bin, "tile-list walk": t_walk, "compact_finish": t_comp},
+            "tile_entries": bins.n_tile_pairs,
+            "roofline": roof(b_boxes, t_a5b),
+            "byte_model": WRAPPER_BOX_BYTES,
+        },
+    }
 
 
 def function_level(dev, workload):
@@ -287,6 +415,7 @@ def sharded_frame(name, world, rank, device, scan_fwd_bwd, sync, steps=10, warmu
         scan_fwd_bwd(p)
     sync()
     t_scan = (time.perf_counter() - t0) / steps
+    t_scan_local = t_scan
     out = {
         "workload": f"{name}: ONE {synthetic.CONFIGS[name]['width']}x{synthetic.CONFIGS[name]['height']} frame, "
                     f"{total_pairs} pairs, cut into {world} slice(s) at pixel-group boundaries nearest k*M/N",
@@ -297,39 +426,60 @@ def sharded_frame(name, world, rank, device, scan_fwd_bwd, sync, steps=10, warmu
     }
     gather_s = scatter_s = None
     err = None
+    # rank 0's rate on its own slice (its slice pairs / its own time, before the max over ranks) = the single-GPU reference
+    slice_rate0 = shards[0].n_pairs / t_scan_local if rank == 0 else 0.0
     if world > 1:
-        t = torch.tensor([t_scan], dtype=torch.float64, device=device)
+        t = torch.tensor([t_scan, slice_rate0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_scan = float(t.item())
+        t_scan, slice_rate0 = float(t[0].item()), float(t[1].item())
         if collectives:
+            # everything a rank does on its own before a collective is agreed on collectively first: a rank that raised
+            # alone would leave the others waiting inside gather / scatter / all_reduce
+            rows, fail = None, None
             try:
                 rows = torch.rand(p.n_groups, 3, device=device)  # per-pixel colour of this slice's groups
-                tg = ts = 0.0
-                reps = 3
-                for it in range(reps + 1):
-                    sync()
-                    t1 = time.perf_counter()
-                    full = sharding.gather_groups(rows, shards, dst=0)
-                    sync()
-                    t2 = time.perf_counter()
-                    back = sharding.scatter_groups(full, shards, like=rows, src=0)
-                    sync()
-                    t3 = time.perf_counter()
-                    if it:  # first round = RCCL channel set-up
-                        tg += t2 - t1
-                        ts += t3 - t2
-                bad = 0.0 if torch.equal(back, rows) else 1.0  # round trip must be the identity
-                tt = torch.tensor([tg / reps, ts / reps, bad], dtype=torch.float64, device=device)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                if float(tt[2]) != 0.0:
-                    err = "gather/scatter round trip is not the identity"
-                else:
-                    gather_s, scatter_s = float(tt[0]), float(tt[1])
-            except Exception as e:  # recorded in the JSON line, never swallowed: a RCCL failure must show in SCALE_r*.json
-                err = repr(e)
+            except Exception as e:  # noqa: BLE001 - reported in the JSON line
+                fail = repr(e)
+            ok = torch.tensor([0.0 if fail else 1.0], dtype=torch.float64, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                err = fail or "another rank could not allocate its rows; collectives skipped on every rank"
+            else:
+                # a failure INSIDE a collective (RCCL refusing to come up hits every rank alike) is recorded in the JSON
+                # line, never swallowed; the rank then takes no further part in this block's collectives
+                try:
+                    tg = ts = 0.0
+                    reps = 3
+                    for it in range(reps + 1):
+                        sync()
+                        t1 = time.perf_counter()
+                        full = sharding.gather_groups(rows, shards, dst=0)
+                        sync()
+                        t2 = time.perf_counter()
+                        back = sharding.scatter_groups(full, shards, like=rows, src=0)
+                        sync()
+                        t3 = time.perf_counter()
+                        if it:  # first round = RCCL channel set-up
+                            tg += t2 - t1
+                            ts += t3 - t2
+                    bad = 0.0 if torch.equal(back, rows) else 1.0  # round trip must be the identity
+                    tt = torch.tensor([tg / reps, ts / reps, bad], dtype=torch.float64, device=device)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    if float(tt[2]) != 0.0:
+                        err = "gather/scatter round trip is not the identity"
+                    else:
+                        gather_s, scatter_s = float(tt[0]), float(tt[1])
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
+    bytes_pp = BYTES_FWD + BYTES_BWD
     out.update({
         "scan_ms_per_step": t_scan * 1e3,
         "pairs_per_s_scan_only": total_pairs / t_scan,
+        "per_gpu_pairs_per_s": total_pairs / t_scan / world,
+        "per_gpu_GBps": bytes_pp * total_pairs / t_scan / 1e9 / world,
+        # strong scaling: frame rate / (N x the rate rank 0 reached on ITS slice, timed on its own before the max over ranks)
+        "efficiency_vs_single_gpu": (total_pairs / t_scan) / (world * slice_rate0) if slice_rate0 > 0 else None,
+        "rank0_slice_pairs_per_s": slice_rate0,
         "frame_gather_ms": None if gather_s is None else gather_s * 1e3,
         "grad_scatter_ms": None if scatter_s is None else scatter_s * 1e3,
         "pairs_per_s_with_gather_scatter": None if gather_s is None else total_pairs / (t_scan + gather_s + scatter_s),
@@ -444,6 +594,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # every rank first times its own band ALONE (device synchronisation only, no barrier): the single-GPU rate that
+    # `efficiency_vs_single_gpu` is taken against — at N = 1 it is the headline itself
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    alone_rate = m * args.steps / (time.perf_counter() - ta)
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -456,14 +614,17 @@ def main():
     fallback = gc.last_fallback_tiles(dev)
 
     stats = torch.tensor([elapsed, float(m)], dtype=torch.float64, device=cdev)
+    alone0 = torch.tensor([alone_rate if rank == 0 else 0.0], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         msum = stats[1:].clone()
         dist.all_reduce(msum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(alone0, op=dist.ReduceOp.MAX)  # rank 0's figure, on every rank
         elapsed, total_pairs = float(tmax.item()), float(msum.item())
     else:
         total_pairs = float(m)
+    rank0_alone = float(alone0.item())
 
     # ---- outside the timed region ------------------------------------------------------------------------------
     walked = gc.last_lookback_tiles(dev)
@@ -547,6 +708,39 @@ def main():
         scan_fwd_bwd.buf.clear()
         torch.cuda.empty_cache()
 
+    # BASELINE.json configs[1] (1920x1080, 100k Gaussians, mean 8 splats per pixel) beside the headline: the same two
+    # launches on its pair list (66 MB per array: cache-resident, which is why the metric is not quoted on it)
+    cfg2_block = None
+    if world == 1 and args.workload != "cfg2":
+        q = synthetic.make_config("cfg2", seed=rank, device=dev)
+        for _ in range(5):
+            scan_fwd_bwd(q)
+        yy, gg = scan_fwd_bwd.buf[("y", q.n_pairs)], scan_fwd_bwd.buf[("g", q.n_pairs)]
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reps, tf, tb = 50, 0.0, 0.0
+        for _ in range(reps):
+            e0.record()
+            gc.grouped_cumprod_forward(q.x, q.key, yy)
+            e1.record()
+            gc.grouped_cumprod_backward(q.x, yy, q.grad_out, q.inv, gg, q.inv_len)
+            e2.record()
+            torch.cuda.synchronize()
+            tf += e0.elapsed_time(e1)
+            tb += e1.elapsed_time(e2)
+        cfg2_block = {
+            "workload": "cfg2: 1920x1080, 100000 Gaussians, mean 8 splats/pixel (Poisson) — BASELINE.json configs[1]",
+            "pairs": q.n_pairs,
+            "pairs_per_s": q.n_pairs / ((tf + tb) / reps * 1e-3),
+            "forward_us": tf / reps * 1e3,
+            "backward_us": tb / reps * 1e3,
+            "fwd_plus_bwd_algorithmic_GBps": (BYTES_FWD + BYTES_BWD) * q.n_pairs / ((tf + tb) / reps * 1e-3) / 1e9,
+            "fwd_plus_bwd_frac_of_hbm_peak": (BYTES_FWD + BYTES_BWD) * q.n_pairs / ((tf + tb) / reps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "arrays of 66 MB each stay in the 256 MB Infinity Cache between launches: not an HBM figure",
+        }
+        del q, yy, gg
+        scan_fwd_bwd.buf.clear()
+        torch.cuda.empty_cache()
+
     if rank == 0:
         ach = BYTES_BWD * m / t_bwd / 1e9
         out = {
@@ -554,6 +748,12 @@ def main():
             "value": total_pairs * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
+            "per_gpu_pairs_per_s": total_pairs * args.steps / elapsed / world,
+            "per_gpu_GBps": (BYTES_FWD + BYTES_BWD) * total_pairs * args.steps / elapsed / 1e9 / world,
+            "per_gpu_frac_of_hbm_peak": (BYTES_FWD + BYTES_BWD) * total_pairs * args.steps / elapsed / 1e9 / world / HBM_PEAK_GBPS,
+            # aggregate rate / (N x the rate rank 0 reached on its own band before the first barrier); 1.0 at N = 1 up to timer noise
+            "efficiency_vs_single_gpu": total_pairs * args.steps / elapsed / (world * rank0_alone),
+            "rank0_alone_pairs_per_s": rank0_alone,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -574,6 +774,7 @@ def main():
                 "world_size_checked": world,
                 "unclipped": unclipped,
                 "live_path_pair": live_pair,
+                "cfg2": cfg2_block,
             },
             "sharded_frames": sharded,
             "roofline": {
@@ -597,6 +798,7 @@ def main():
             },
         }
         if world == 1:
+            out["wrapper_level"] = wrapper_level(dev, args.workload)
             out["function_level"] = function_level(dev, args.workload)
             out["caller_level"] = caller_level(dev, args.workload)
         if world == 1 and args.cpu_sample > 0:

@@ -168,6 +168,22 @@ def make_scene_config(name, seed=0, device="cpu"):
     return make_scene(c["gaussians"], c["width"] - 1, c["height"] - 1, c["mean_depth"], seed, device)
 
 
+def make_scene_pairs(name, seed=0, device="cuda"):
+    """The pair list the reference's Function builds for one camera of a synthetic scene of config `name`, as its
+    `_create_alpha_brend` / `grad_cumsum` receive it (gs_model.py:601-607, :630-636): Gaussian-major rects int32[M,2]
+    (uitility.py:336-366), the anti-opacity 1 - o*g of every pair (gs_model.py:533-535) and a gradient per pair.
+    Returns (scene dict, rects, anti_opacity, grad).  Needs the HIP library (rect expansion runs on the device)."""
+    from . import raster
+
+    sc = make_scene_config(name, seed=seed, device=device)
+    rects, owner = raster.expand_rects(sc["start"], sc["end"], sc["width"], sc["height"], with_gaussian=True)
+    g = torch.Generator(device=rects.device).manual_seed(int(seed) + 1)
+    gk = torch.rand(rects.size(0), device=rects.device, generator=g)
+    anti = 1.0 - sc["opacity"].reshape(-1)[owner.long()] * gk
+    grad = torch.randn(rects.size(0), device=rects.device, generator=g)
+    return sc, rects, anti, grad
+
+
 def ring_cameras(n_cam, width, height, radius=3.2, device="cpu"):
     """World->camera [R|t] (n,3,4), intrinsics (n,3,3) and (n,2) sizes of cameras on a ring looking at the origin
     (COLMAP convention: x right, y down, z forward) — the camera side of the caller tests and benches (row f4)."""

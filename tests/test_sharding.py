@@ -246,6 +246,10 @@ def test_bench_sharded_frame_block_gloo_rehearsal(world):
     assert o0["collective_error"] is None
     assert o0["frame_gather_ms"] is not None and o0["grad_scatter_ms"] is not None
     assert o0["pairs_per_s_with_gather_scatter"] < o0["pairs_per_s_scan_only"]
+    # SURVEY §8e reporting: per-GPU rate / GB/s and efficiency against N copies of rank 0's own slice rate
+    assert abs(o0["per_gpu_pairs_per_s"] * world - o0["pairs_per_s_scan_only"]) <= 1e-6 * o0["pairs_per_s_scan_only"]
+    assert abs(o0["per_gpu_GBps"] - 32 * o0["per_gpu_pairs_per_s"] / 1e9) <= 1e-9 * o0["per_gpu_GBps"] + 1e-12
+    assert o0["rank0_slice_pairs_per_s"] > 0 and 0.0 < o0["efficiency_vs_single_gpu"] <= 1.5
     whole = synthetic.make_config("cfg1", seed=0)  # same seed: the slices are a cut of this frame's run lengths
     assert o0["total_pairs"] == whole.n_pairs == sum(o0["pairs_per_rank"])
     assert sum(o0["groups_per_rank"]) == whole.n_groups

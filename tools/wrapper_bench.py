@@ -33,15 +33,7 @@ def timeit(fn, iters=5, warmup=2):
 
 
 def scene_inputs(cfg, dev, seed=0):
-    """The pair list as the reference builds it for one camera: Gaussian-major rects (uitility.py:336-366) and the
-    anti-opacity of every pair (gs_model.py:533-535) of a synthetic scene of the config's shape."""
-    sc = synthetic.make_scene_config(cfg, seed=seed, device=dev)
-    rects, owner = raster.expand_rects(sc["start"], sc["end"], sc["width"], sc["height"], with_gaussian=True)
-    g = torch.Generator(device=dev).manual_seed(seed + 1)
-    gk = torch.rand(rects.size(0), device=dev, generator=g)
-    anti = 1.0 - sc["opacity"].reshape(-1)[owner.long()] * gk
-    grad = torch.randn(rects.size(0), device=dev, generator=g)
-    return sc, rects, anti, grad
+    return synthetic.make_scene_pairs(cfg, seed=seed, device=dev)
 
 
 def main():
@@ -80,6 +72,15 @@ def main():
             vals, keep = raster.compact_finish(incl, anti, 0)
             st["dropped_pairs"] = int(m - vals.numel())
             st["key_range_ms"] = timeit(lambda: raster.rects_key_bits(rects), iters)
+            # the boxes route, stage by stage
+            st["boxes_bin_tiles_ms"] = timeit(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h), iters)
+            bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
+            st["boxes_box_offsets_ms"] = timeit(lambda: raster.box_offsets(sc["start"], sc["end"], w, h), iters)
+            boff = raster.box_offsets(sc["start"], sc["end"], w, h)
+            st["boxes_walk_cumprod_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0), iters)
+            st["boxes_walk_reverse_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, grad, 2), iters)
+            st["tile_entries"] = bins.n_tile_pairs
+            del bins, boff
             y = torch.empty_like(anti)
             st["plain_scan_same_size_ms"] = timeit(lambda: gc.grouped_cumprod_forward(anti, sk, y), iters)
             del sk, idx, incl, y, vals, keep

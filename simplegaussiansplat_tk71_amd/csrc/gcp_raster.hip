@@ -864,16 +864,22 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
 
 // per Gaussian: sum its tile slots in order, expand the moments into the four gradients
 __global__ void k_grad_reduce(const float* __restrict__ partial, const int* __restrict__ tile_off,
-                              const float* __restrict__ vinv, i64 n, i64 capacity, float* grad_mean, float* grad_vinv,
-                              float* grad_opacity, float* grad_l) {
+                              const int* __restrict__ tile_start, int n_tiles, const float* __restrict__ vinv, i64 n,
+                              i64 capacity, float* grad_mean, float* grad_vinv, float* grad_opacity, float* grad_l) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   float r[kGradVals];
 #pragma unroll
   for (int v = 0; v < kGradVals; ++v) r[v] = 0.0f;
-  // (a Gaussian whose entries did not fit below the capacity of a capture-safe binning was never listed: zeros)
-  const i64 e1 = (i64)tile_off[g + 1] <= capacity ? (i64)tile_off[g + 1] : (i64)tile_off[g];
-  for (i64 e = tile_off[g]; e < e1; ++e)
+  // Only slots the blend kernel wrote are summed: a Gaussian's entries [tile_off[g], tile_off[g+1]) count iff they lie
+  // inside what the binning LISTED (tile_start[n_tiles] entries: everything with exact binning; with a capture-safe
+  // capacity the Gaussians that fit; nothing at all when the int32 prefix sums wrapped at > 2^31 entries — the offsets
+  // behind the wrap are negative or decreasing, and even the ones before it point at slots nobody wrote).  Zeros otherwise.
+  const i64 listed = min((i64)tile_start[n_tiles], capacity);
+  const i64 e0 = tile_off[g];
+  i64 e1 = tile_off[g + 1];
+  if (e0 < 0 || e1 < e0 || e1 > listed) e1 = e0 < 0 ? 0 : e0;
+  for (i64 e = (e0 < 0 ? 0 : e0); e < e1; ++e)
 #pragma unroll
     for (int v = 0; v < kGradVals; ++v) r[v] += partial[e * kGradVals + v];
   const float A = vinv[4 * g], B = vinv[4 * g + 1], C = vinv[4 * g + 2], D = vinv[4 * g + 3];
@@ -1394,8 +1400,8 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
     GCP_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n_gauss + 255) / 256)), dim3(256), 0, stream,
-                     (const float*)partial, tile_off, vinv, (i64)n_gauss, (i64)n_tile_pairs, grad_mean, grad_vinv, grad_opacity,
-                     grad_l);
+                     (const float*)partial, tile_off, tile_start, tg.tx * tg.ty, vinv, (i64)n_gauss, (i64)n_tile_pairs, grad_mean,
+                     grad_vinv, grad_opacity, grad_l);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

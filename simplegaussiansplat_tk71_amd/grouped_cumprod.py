@@ -32,6 +32,7 @@ __all__ = [
     "grouped_cumprod_forward_carry",
     "grouped_cumsum_forward_carry",
     "grouped_cumsum_reverse_carry",
+    "Workspace",
     "check_groups",
     "last_fallback_tiles",
     "last_lookback_tiles",
@@ -39,7 +40,28 @@ __all__ = [
     "tile_elems",
 ]
 
-_workspaces = {}  # (device index, stream handle) -> uint8 tensor
+class Workspace:
+    """Scratch of the scans (include/grouped_cumprod_hip.h "Workspace"): a launch counter and two sets of tile descriptors,
+    zeroed once and self-maintaining afterwards.  Launches that share one must be ORDERED (one stream); give every stream
+    that scans concurrently its own.  Pass it as `workspace=` to any scan of this module, or let the module keep one per
+    (device, stream) — see `_workspace`.  A HIP graph that captured a scan holds this buffer's address: keep the object
+    alive as long as the graph (the module's own cache never drops a workspace that was used during a capture)."""
+
+    def __init__(self, device, n_elements):
+        device = torch.device(device)
+        self.capacity = int(n_elements)
+        need = _lib.load().gcp_workspace_bytes(self.capacity)
+        # launch counter + two alternating sets of tile descriptors: must start zeroed
+        self.tensor = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
+        self.pinned = False  # a captured graph has baked the address in
+
+    def fits(self, n):
+        return self.capacity >= n
+
+
+_workspaces = {}   # (device index, stream handle) -> Workspace, in least-recently-used order
+_retired = []      # workspaces a captured graph may still point at, replaced by larger ones: never freed
+_MAX_CACHED = 16   # per process; torch's stream pool hands out 32 streams per device and priority at most
 
 
 def _require(cond, msg):
@@ -74,31 +96,52 @@ def _no_alias(out, out_name, *inputs):
 
 
 def _workspace(device, stream_handle, n):
-    """Scratch of the current (device, stream): reused across calls, grown geometrically."""
+    """The module's own scratch of the current (device, stream): reused across calls, grown geometrically, at most
+    _MAX_CACHED of them alive (least recently used first out).  Keyed by the HIP stream HANDLE: torch's streams come
+    from a per-device pool and are never destroyed, so one handle is one stream for the life of the process — two
+    `torch.cuda.Stream` objects that share a handle ARE the same stream, and their launches are ordered.  (An external
+    stream that is destroyed and whose handle is later reused has drained by then: hipStreamDestroy releases the handle
+    only when its work has completed.)  A workspace in use while the stream is capturing is pinned: the graph replays
+    with its address."""
     key = (device.index, stream_handle)
-    hit = _workspaces.get(key)
-    if hit is not None and hit[1] >= n:
-        return hit[0]
-    need = _lib.load().gcp_workspace_bytes(n + n // 2)
-    # launch counter + two alternating sets of tile descriptors: must start zeroed (include/grouped_cumprod_hip.h)
-    ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
-    _workspaces[key] = (ws, n + n // 2)
-    return ws
+    ws = _workspaces.pop(key, None)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ws is None or not ws.fits(n):
+        if ws is not None and ws.pinned:
+            _retired.append(ws)
+        ws = Workspace(device, n + n // 2)
+    ws.pinned = ws.pinned or capturing
+    _workspaces[key] = ws  # most recently used last
+    while len(_workspaces) > _MAX_CACHED:
+        for k, w in _workspaces.items():
+            if not w.pinned and k != key:
+                del _workspaces[k]
+                break
+        else:
+            break
+    return ws.tensor
 
 
-def _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n=()):
+def _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n=(), workspace=None):
     lib = _lib.load()
     if device.index != torch.cuda.current_device():
         with torch.cuda.device(device):
-            return _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n)
+            return _launch(fn_name, device, n, ptrs_before_n, ptrs_after_n, workspace)
     stream = torch.cuda.current_stream(device).cuda_stream
-    ws = _workspace(device, stream, n)
+    if workspace is not None:
+        _require(isinstance(workspace, Workspace), "workspace: expected a grouped_cumprod.Workspace")
+        _require(workspace.tensor.device == device, f"workspace: on {workspace.tensor.device}, expected {device}")
+        _require(workspace.fits(n), f"workspace: sized for {workspace.capacity} elements, this call has {n}")
+        workspace.pinned = workspace.pinned or torch.cuda.is_current_stream_capturing()
+        ws = workspace.tensor
+    else:
+        ws = _workspace(device, stream, n)
     status = getattr(lib, fn_name)(*ptrs_before_n, n, *ptrs_after_n, ws.data_ptr(), ws.numel(), stream)
     if status:
         _lib.check(status, fn_name)
 
 
-def _forward(fn_name, x, key, y):
+def _forward(fn_name, x, key, y, workspace=None):
     _require(isinstance(key, torch.Tensor), "pixel_index: expected a torch.Tensor")
     n = key.numel()  # reference: n = pixel_index.numel() (grouped_cumprod_forward.cu:13)
     dev = key.device
@@ -108,26 +151,26 @@ def _forward(fn_name, x, key, y):
     if n == 0:
         return
     _no_alias(y, "out", (x, "unti_opacity"), (key, "pixel_index"))
-    _launch(fn_name, dev, n, (x.data_ptr(), key.data_ptr(), y.data_ptr()))
+    _launch(fn_name, dev, n, (x.data_ptr(), key.data_ptr(), y.data_ptr()), workspace=workspace)
 
 
-def grouped_cumprod_forward(unti_opacity, pixel_index, out):
+def grouped_cumprod_forward(unti_opacity, pixel_index, out, *, workspace=None):
     """out[i] = prod of unti_opacity over the run of equal adjacent pixel_index up to i.
 
     reference: cuda_kernel/grouped_cumprod_forward.cu:6-24.
     """
-    _forward("gcp_cumprod_forward", unti_opacity, pixel_index, out)
+    _forward("gcp_cumprod_forward", unti_opacity, pixel_index, out, workspace)
 
 
-def grouped_cumsum_forward(unti_opacity, pixel_index, out):
+def grouped_cumsum_forward(unti_opacity, pixel_index, out, *, workspace=None):
     """Same with a running sum.  reference: cuda_kernel/grouped_cumsum_forward.cu:6-24."""
-    _forward("gcp_cumsum_forward", unti_opacity, pixel_index, out)
+    _forward("gcp_cumsum_forward", unti_opacity, pixel_index, out, workspace)
 
 
-def grouped_cumsum_reverse(x, key, out):
+def grouped_cumsum_reverse(x, key, out, *, workspace=None):
     """Suffix sums inside each run: flip -> grouped_cumsum_forward -> flip of the
     reference (gs_model.py:716-722) in one pass.  Not in the reference module."""
-    _forward("gcp_cumsum_reverse", x, key, out)
+    _forward("gcp_cumsum_reverse", x, key, out, workspace)
 
 
 def _forward_indexed(fn_name, x, sorted_key, index, y):
@@ -192,7 +235,7 @@ def grouped_cumsum_reverse_carry(x, inv, carry, out):
     _forward_carry("gcp_cumsum_reverse_carry", x, inv, carry, out)
 
 
-def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_len):
+def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_len, *, workspace=None):
     """grad_in[j] = sum_{i=j}^{inv_len[inv[j]]-1} grad_out[i] * param_cumprod[i] / p'_j.
 
     reference: cuda_kernel/grouped_cumprod_backward.cu:9-65 (p'_j = param[j] or 1e-8
@@ -220,6 +263,7 @@ def grouped_cumprod_backward(param, param_cumprod, grad_out, inv, grad_in, inv_l
         (param.data_ptr(), param_cumprod.data_ptr(), grad_out.data_ptr(), inv.data_ptr(), grad_in.data_ptr(),
          inv_len.data_ptr()),
         (inv_len.numel(),),
+        workspace=workspace,
     )
 
 
@@ -247,7 +291,7 @@ def _last_stat(fn_name, device):
         hit = _workspaces.get((device.index, stream))
         if hit is None:
             return 0
-        status = getattr(lib, fn_name)(hit[0].data_ptr(), stream, ctypes.byref(out))
+        status = getattr(lib, fn_name)(hit.tensor.data_ptr(), stream, ctypes.byref(out))
     _lib.check(status, fn_name)
     return out.value
 

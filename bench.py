@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# host threads that finished a parallel region go to sleep instead of spinning: the CPU baseline's legs (OpenMP C port,
+# torch's own pool) otherwise disturb each other on the shared cores of the GPU box
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -83,29 +87,54 @@ def cpu_baseline(p, sample_pairs):
     x, key, inv, go = (t[:s].cpu().contiguous() for t in (p.x, p.key, p.inv, p.grad_out))
     il = inv_len[:g].contiguous()
     threads = max(1, min(16, os.cpu_count() or 1, co.max_threads()))
-    y = co.cumprod_forward_mt(x, il, threads)
-    t_f = _median_time(lambda: co.cumprod_forward_mt(x, il, threads), reps=5, warmup=1)
-    t_b = _median_time(lambda: co.cumprod_backward_mt(x, y, go, inv, il, threads), reps=5, warmup=1)
-    # single thread, a quarter of the sample
+
+    class one_core:
+        """Single-thread legs run pinned to one of the cores this process may use: on a shared host an unpinned thread
+        is moved between cores (and memory domains) from one run to the next, worth 10 % of a 20 ms leg."""
+
+        def __enter__(self):
+            self.old = None
+            try:
+                self.old = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, {sorted(self.old)[len(self.old) // 2]})
+            except (AttributeError, OSError):
+                self.old = None
+
+        def __exit__(self, *exc):
+            if self.old:
+                os.sched_setaffinity(0, self.old)
+
+    # single thread first (pinned; before any OpenMP team exists), a quarter of the sample
     g1, s1 = prefix(max(1, sample_pairs // 4))
     x1, k1, i1, go1, il1 = x[:s1].contiguous(), key[:s1].contiguous(), inv[:s1].contiguous(), go[:s1].contiguous(), inv_len[:g1].contiguous()
-    y1 = co.cumprod_forward(x1, k1)
-    t_f1 = _median_time(lambda: co.cumprod_forward(x1, k1), reps=5, warmup=1)
-    t_b1 = _median_time(lambda: co.cumprod_backward(x1, y1, go1, i1, il1), reps=5, warmup=1)
+    ref_fwd = None
+    with one_core():
+        y1 = co.cumprod_forward(x1, k1)
+        t_f1 = _median_time(lambda: co.cumprod_forward(x1, k1), reps=5, warmup=2, min_s=0.5)
+        t_b1 = _median_time(lambda: co.cumprod_backward(x1, y1, go1, i1, il1), reps=5, warmup=1)
+        # the reference's OWN forward (grouped_cumprod_forward.cu, unmodified, rocThrust CPP backend: sequential) where the
+        # build container compiled it into oracle/_ref/; output allocated and touched before the timed calls
+        host = oref.load("grouped_cumprod_ref_host")
+        if host is not None:
+            y_ref = torch.zeros_like(x1)
+            t_ref = _median_time(lambda: host.grouped_cumprod_forward(x1, k1, y_ref), reps=5, warmup=2, min_s=0.5)
+            ref_fwd = leg(s1, t_ref, unit="pairs/s (forward only)", cores=1, kind="reference",
+                          sample=f"{s1} pairs, cuda_kernel/grouped_cumprod_forward.cu compiled for the host (oracle/_ref)",
+                          equals_port=bool(torch.equal(y_ref, y1)))
     # the "pure-PyTorch torch.cumprod path" of BASELINE.json (per-group torch.cumprod), forward only
     g8, s8 = prefix(min(4_000_000, s))
     x8, k8 = x[:s8].contiguous(), key[:s8].contiguous()
-    t_tp = _median_time(lambda: tp.grouped_cumprod(x8, k8), reps=5, warmup=1)
-    # the reference's OWN forward (grouped_cumprod_forward.cu, unmodified, rocThrust CPP backend: sequential) where the
-    # build container compiled it into oracle/_ref/; output allocated and touched before the timed calls
-    ref_fwd = None
-    host = oref.load("grouped_cumprod_ref_host")
-    if host is not None:
-        y_ref = torch.zeros_like(x1)
-        t_ref = _median_time(lambda: host.grouped_cumprod_forward(x1, k1, y_ref), reps=5, warmup=1)
-        ref_fwd = leg(s1, t_ref, unit="pairs/s (forward only)", cores=1, kind="reference",
-                      sample=f"{s1} pairs, cuda_kernel/grouped_cumprod_forward.cu compiled for the host (oracle/_ref)",
-                      equals_port=bool(torch.equal(y_ref, y1)))
+    # (one torch thread, pinned like the other single-thread legs: with torch's own pool the leg — large temporaries, the
+    # allocator, page faults — moved by +-20 % from one run to the next on the shared host)
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    with one_core():
+        t_tp = _median_time(lambda: tp.grouped_cumprod(x8, k8), reps=5, warmup=2, min_s=0.5)
+    torch.set_num_threads(old_threads)
+    # OpenMP over pixel groups: the headline figure
+    y = co.cumprod_forward_mt(x, il, threads)
+    t_f = _median_time(lambda: co.cumprod_forward_mt(x, il, threads), reps=5, warmup=1)
+    t_b = _median_time(lambda: co.cumprod_backward_mt(x, y, go, inv, il, threads), reps=5, warmup=1)
     med = t_f[0] + t_b[0]
     return {
         "value": s / med,
@@ -120,7 +149,7 @@ def cpu_baseline(p, sample_pairs):
                           "fwd_ms": t_f1[0] * 1e3, "bwd_ms": t_b1[0] * 1e3},
         "port_forward_single_thread": leg(s1, t_f1, unit="pairs/s (forward only)", cores=1, kind="port",
                                           sample=f"{s1} pairs, oracle/gcp_oracle.c forward alone — compare with reference_host_forward"),
-        "torch_cumprod_path_forward": leg(s8, t_tp, unit="pairs/s (forward only)", threads=torch.get_num_threads(),
+        "torch_cumprod_path_forward": leg(s8, t_tp, unit="pairs/s (forward only)", threads=1,
                                           sample=f"{s8} pairs, oracle/torch_path.py (per-group torch.cumprod)"),
         "reference_host_forward": ref_fwd,
     }

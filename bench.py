@@ -238,14 +238,15 @@ def wrapper_level(dev, workload):
         ts.sort()
         return ts[len(ts) // 2]
 
-    t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits))
-    t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, key_bits=bits))
+    t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h)))
+    t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h)))
+    t_a5_kb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits))
     t_a5_rb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"))
     t_a5b = timed(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"))
     t_a6b = timed(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h))
     # stages of the rects route
-    t_sort = timed(lambda: raster.sort_rects(rects, bits))
-    sk, idx = raster.sort_rects(rects, bits)
+    t_sort = timed(lambda: raster.sort_rects(rects, image_size=(w, h)))
+    sk, idx = raster.sort_rects(rects, image_size=(w, h))
     incl = torch.empty_like(anti)
     t_scan = timed(lambda: gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl))
     t_rev = timed(lambda: gc.grouped_cumsum_reverse_indexed(grad, sk, idx, incl))
@@ -272,14 +273,16 @@ def wrapper_level(dev, workload):
         "workload": f"{workload} scene: {w + 1}x{h + 1}, {int(sc['start'].size(0))} Gaussians",
         "pairs": m,
         "kept_pairs": kept,
-        "key_bits": bits,
+        "sort": f"compact pixel ids y*{w + 1}+x: {max(1, (h * (w + 1) + w).bit_length())} bits in 3 passes (image_size given); "
+                f"{bits}-bit keys y*10000+x with key_bits",
         "create_alpha_brend_ms": t_a5,
+        "create_alpha_brend_key_bits_ms": t_a5_kb,
         "grad_cumsum_ms": t_a6,
         "create_alpha_brend_key_range_read_back_ms": t_a5_rb,
         "create_alpha_brend_pairs_per_s": m / (t_a5 * 1e-3),
         "grad_cumsum_pairs_per_s": m / (t_a6 * 1e-3),
         "roofline": roof(b_rects, t_a5),
-        "stages_ms": {"sort_rects (3 radix passes of 8 bits)": t_sort, "indexed scan (cumprod)": t_scan, "indexed scan (suffix sum)": t_rev,
+        "stages_ms": {"sort_rects (3 radix passes)": t_sort, "indexed scan (cumprod)": t_scan, "indexed scan (suffix sum)": t_rev,
                       "compact_finish": t_comp},
         "stage_rooflines": {"sort": roof(sum(WRAPPER_BYTES["sort"].values()), t_sort),
                             "indexed scan": roof(sum(WRAPPER_BYTES["indexed scan"].values()), t_scan),

@@ -277,10 +277,13 @@ int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uin
                        int32_t* index_out, void* ws, size_t ws_bytes, void* stream);
 /* The same sort with the reference's pixel key computed on the fly from its rect list (gs_model.py:538-541, :546:
  * key = y * 10000 + x of rects_xy[i] = (x, y)): the int32 key array of `unique()` never exists.  keys_out receives
- * the sorted keys (what `sorted_inv` is at gs_model.py:547), index_out the permutation.  key_bits must cover
- * height * 10000 + width (24 for 1920x1080, 25 for 3840x2160). */
-int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
-                   void* ws, size_t ws_bytes, void* stream);
+ * the sorted keys (what `sorted_inv` is at gs_model.py:547), index_out the permutation.
+ *   id_width == 0: key_bits must cover max(y) * 10000 + max(x) (24 at 1920x1080, 25 at 3840x2160);
+ *   id_width  > 0: the caller knows the image: every x < id_width (= width + 1).  The passes then run on the compact
+ *     ids y * id_width + x (same order, fewer bits, narrower digits: 3 x 7 bits at 1920x1080) and the last pass writes
+ *     the reference's keys; key_bits must cover max(y) * id_width + max(x) and be <= 24. */
+int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, int32_t id_width, uint32_t* keys_out,
+                   int32_t* index_out, void* ws, size_t ws_bytes, void* stream);
 /* max over i of (y_i * 10000 + x_i) and min over i of min(x_i, y_i), written to out_dev[0], out_dev[1] (device int32[2]):
  * what a caller needs to choose key_bits when it does not know the image size. */
 int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream);

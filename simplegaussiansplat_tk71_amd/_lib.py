@@ -72,7 +72,7 @@ SIGNATURES = {
     "gcp_unsort_finish": (ctypes.c_int, [_c_void_p] * 5 + [_i64, _i32, _c_void_p]),
     "gcp_sort_workspace_bytes": (_sz, [_i64]),
     "gcp_sort_pairs_u32": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
-    "gcp_sort_rects": (ctypes.c_int, [_c_void_p, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
+    "gcp_sort_rects": (ctypes.c_int, [_c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rects_key_range": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _c_void_p]),
     "gcp_compact_workspace_bytes": (_sz, [_i64]),
     "gcp_compact_finish": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),

@@ -361,9 +361,34 @@ __device__ __forceinline__ void count_runs(int* h, unsigned d, int lane) {
   }
 }
 
+// Digit of a pass: (key >> shift) & dmask.  With idw > 0 the M-sized sort runs on COMPACT pixel ids y * idw + x (idw =
+// image width + 1) instead of the reference's y * 10000 + x — the same order, 21 instead of 24 significant bits at
+// 1920x1080, so three passes of 7 bits: half as many digit runs per chunk, twice as long, and the scattered stores of a
+// pass come that much closer to whole cache lines.  The last pass turns the ids back into the reference's keys.
+struct SortPass { int shift; unsigned dmask; int idw; int restore; float inv_idw; };
+
 template <bool RECTS>
-__global__ __launch_bounds__(256) void k_sort_hist2(const unsigned* key, i64 n, int shift, int* hist, int nsuper, int sub, int xcd_remap,
+__device__ __forceinline__ unsigned load_sort_key(const unsigned* key, i64 i, int idw) {
+  if (!RECTS) return key[i];
+  const int2 r = reinterpret_cast<const int2*>(key)[i];
+  return (unsigned)(r.y * (idw ? idw : 10000) + r.x);
+}
+
+// id -> y * 10000 + x with y = id / idw, x = id % idw (ids < 2^24: exact in fp32; one correction step either way)
+__device__ __forceinline__ unsigned restore_key(unsigned id, int idw, float inv_idw) {
+  unsigned y = (unsigned)((float)id * inv_idw);
+  int x = (int)id - (int)y * idw;
+  if (x < 0) { --y; x += idw; }
+  else if (x >= idw) { ++y; x -= idw; }
+  return y * 10000u + (unsigned)x;
+}
+
+template <bool RECTS>
+__global__ __launch_bounds__(256) void k_sort_hist2(const unsigned* key, i64 n, const SortPass ps, int* hist, int nsuper, int sub, int xcd_remap,
                                                     int vec /*the source is 16-byte aligned*/) {
+  const int shift = ps.shift;
+  const unsigned dmask = ps.dmask;
+  const int kmul = ps.idw ? ps.idw : 10000;
   __shared__ int h[256];
   const i64 super = sort_chunk(blockIdx.x, nsuper, xcd_remap);
   if (super < 0) return;
@@ -380,17 +405,17 @@ __global__ __launch_bounds__(256) void k_sort_hist2(const unsigned* key, i64 n, 
       if (RECTS) {
         const int4 a = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(key) + p);
         const int4 b = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(key) + p + 2);
-        k4[0] = (unsigned)(a.y * 10000 + a.x); k4[1] = (unsigned)(a.w * 10000 + a.z);
-        k4[2] = (unsigned)(b.y * 10000 + b.x); k4[3] = (unsigned)(b.w * 10000 + b.z);
+        k4[0] = (unsigned)(a.y * kmul + a.x); k4[1] = (unsigned)(a.w * kmul + a.z);
+        k4[2] = (unsigned)(b.y * kmul + b.x); k4[3] = (unsigned)(b.w * kmul + b.z);
       } else {
         const uint4 a = *reinterpret_cast<const uint4*>(key + p);
         k4[0] = a.x; k4[1] = a.y; k4[2] = a.z; k4[3] = a.w;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k4[j] = (k4[j] >> shift) & 255u;
+      for (int j = 0; j < 4; ++j) k4[j] = (k4[j] >> shift) & dmask;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k4[j] = (p + j < end) ? ((load_key<RECTS>(key, p + j) >> shift) & 255u) : 256u;
+      for (int j = 0; j < 4; ++j) k4[j] = (p + j < end) ? ((load_sort_key<RECTS>(key, p + j, ps.idw) >> shift) & dmask) : 256u;
     }
     // element j of every lane: neighbouring lanes hold keys 4 apart — still mostly equal upper digits
 #pragma unroll
@@ -421,10 +446,12 @@ constexpr int kSortWaves = kBigChunk / 512;  // 8 steps of 64 keys per wave and 
 
 template <bool FIRST, bool RECTS>
 __global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigned* key, const unsigned* val, unsigned* key_out,
-                                                                    unsigned* val_out, i64 n, int shift, const int* hist_excl,
+                                                                    unsigned* val_out, i64 n, const SortPass ps, const int* hist_excl,
                                                                     int nsuper, int sub, int xcd_remap) {
   const i64 super = sort_chunk(blockIdx.x, nsuper, xcd_remap);
   if (super < 0) return;
+  const int shift = ps.shift;
+  const unsigned dmask = ps.dmask;
   __shared__ unsigned s_key[kBigChunk];
   __shared__ unsigned s_val[kBigChunk];
   __shared__ int off[kSortWaves][256];  // (A) per-wave digit counts -> (B) first LDS slot of (wave, digit)
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigne
     for (int st = 0; st < kSteps; ++st) {
       const i64 i = wbase + st * 64 + lane;
       const bool valid = i < n;
-      k[st] = valid ? load_key<RECTS>(key, i) : 0u;  // (non-temporal loads here: no difference, measured)
+      k[st] = valid ? load_sort_key<RECTS>(key, i, ps.idw) : 0u;  // (non-temporal loads here: no difference, measured)
       v[st] = FIRST ? (unsigned)i : (valid ? val[i] : 0u);
     }
     for (int d = lane; d < 256; d += 64) off[w][d] = 0;
@@ -460,7 +487,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigne
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {
       const bool valid = wbase + st * 64 + lane < n;
-      const unsigned d = (k[st] >> shift) & 255u;
+      const unsigned d = (k[st] >> shift) & dmask;
       unsigned plo, phi;
       digit_peers(d, __ballot(valid), plo, phi);
       const int rank = (int)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
@@ -497,7 +524,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigne
 #pragma unroll
     for (int st = 0; st < kSteps; ++st) {  // (C) staged into LDS in digit order: independent reads and writes
       if (wbase + st * 64 + lane < n) {
-        const int pos = off[w][(k[st] >> shift) & 255u] + slot[st];
+        const int pos = off[w][(k[st] >> shift) & dmask] + slot[st];
         s_key[pos] = k[st];
         s_val[pos] = v[st];
       }
@@ -506,9 +533,9 @@ __global__ __launch_bounds__(64 * kSortWaves) void k_sort_scatter2(const unsigne
     const int nvalid = (int)((n - bbase < kBigChunk) ? (n - bbase) : kBigChunk);
     for (int i = tid; i < nvalid; i += kThreadsS) {  // (D) coalesced copy-out: consecutive lanes, consecutive slots
       const unsigned kk = s_key[i];
-      const i64 g = (i64)i + gdelta[(kk >> shift) & 255u];
+      const i64 g = (i64)i + gdelta[(kk >> shift) & dmask];
       if ((unsigned long long)g < (unsigned long long)n) {  // always true; keeps a broken histogram from becoming a wild store
-        key_out[g] = kk;
+        key_out[g] = ps.restore ? restore_key(kk, ps.idw, ps.inv_idw) : kk;
         val_out[g] = s_val[i];
       }
     }
@@ -1455,9 +1482,10 @@ size_t gcp_sort_workspace_bytes(int64_t n) {
   return b;
 }
 
-static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
-                     void* ws, size_t ws_bytes, hipStream_t stream) {
-  if (n < 0 || n > 0x7fffffffLL || key_bits < 1 || key_bits > 32) return GCP_ERR_INVALID_ARGUMENT;
+static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key_bits, int32_t id_width, uint32_t* keys_out,
+                     int32_t* index_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || n > 0x7fffffffLL || key_bits < 1 || key_bits > 32 || id_width < 0 || (id_width && (!rects || key_bits > 24)))
+    return GCP_ERR_INVALID_ARGUMENT;
   if (n == 0) return GCP_OK;
   if (!keys_in || !keys_out || !index_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_sort_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
@@ -1476,30 +1504,37 @@ static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key
   int* sws = (int*)p;
   unsigned* keyX = keys_out;
   unsigned* valX = (unsigned*)index_out;
+  // passes of at most 8 bits, all of the same width: 24 bits -> 3 x 8, 21 bits -> 3 x 7, 25 bits -> 4 x 7
   const int passes = (key_bits + 7) / 8;
+  const int width = (key_bits + passes - 1) / passes;
   const unsigned* ks = keys_in;
   const unsigned* vs = nullptr;
   for (int pass = 0; pass < passes; ++pass) {
     const bool to_x = ((passes - 1 - pass) & 1) == 0;  // the last pass lands in the caller's buffers
     unsigned* kd = to_x ? keyX : keyY;
     unsigned* vd = to_x ? valX : valY;
-    const int shift = 8 * pass;
+    SortPass ps;
+    ps.shift = width * pass;
+    ps.dmask = (1u << width) - 1u;
+    ps.idw = id_width;
+    ps.restore = (id_width && pass == passes - 1) ? 1 : 0;
+    ps.inv_idw = id_width ? 1.0f / (float)id_width : 0.0f;
     const bool src_rects = pass == 0 && rects;
     const int vec = (((uintptr_t)ks & 15u) == 0) ? 1 : 0;  // (the ping-pong buffers always are; a caller's view may not be)
-    if (src_rects) hipLaunchKernelGGL((k_sort_hist2<true>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nsuper, sub, xcd_remap, vec);
-    else hipLaunchKernelGGL((k_sort_hist2<false>), grid, block, 0, stream, ks, (i64)n, shift, hist, (int)nsuper, sub, xcd_remap, vec);
+    if (src_rects) hipLaunchKernelGGL((k_sort_hist2<true>), grid, block, 0, stream, ks, (i64)n, ps, hist, (int)nsuper, sub, xcd_remap, vec);
+    else hipLaunchKernelGGL((k_sort_hist2<false>), grid, block, 0, stream, ks, (i64)n, ps, hist, (int)nsuper, sub, xcd_remap, vec);
     GCP_HIP(hipGetLastError());
     const int st = launch_excl_scan(hist, hist_ex, 256 * nsuper, sws, stream);
     if (st != GCP_OK) return st;
     const dim3 sblock(64 * kSortWaves);
     if (src_rects)
-      hipLaunchKernelGGL((k_sort_scatter2<true, true>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+      hipLaunchKernelGGL((k_sort_scatter2<true, true>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, ps, (const int*)hist_ex,
                          (int)nsuper, sub, xcd_remap);
     else if (pass == 0)
-      hipLaunchKernelGGL((k_sort_scatter2<true, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+      hipLaunchKernelGGL((k_sort_scatter2<true, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, ps, (const int*)hist_ex,
                          (int)nsuper, sub, xcd_remap);
     else
-      hipLaunchKernelGGL((k_sort_scatter2<false, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, shift, (const int*)hist_ex,
+      hipLaunchKernelGGL((k_sort_scatter2<false, false>), grid, sblock, 0, stream, ks, vs, kd, vd, (i64)n, ps, (const int*)hist_ex,
                          (int)nsuper, sub, xcd_remap);
     GCP_HIP(hipGetLastError());
     ks = kd;
@@ -1510,12 +1545,12 @@ static int sort_impl(const unsigned* keys_in, bool rects, int64_t n, int32_t key
 
 int gcp_sort_pairs_u32(const uint32_t* keys_in, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out,
                        void* ws, size_t ws_bytes, void* stream_) {
-  return sort_impl(keys_in, false, n, key_bits, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
+  return sort_impl(keys_in, false, n, key_bits, 0, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
 }
 
-int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, uint32_t* keys_out, int32_t* index_out, void* ws,
-                   size_t ws_bytes, void* stream_) {
-  return sort_impl((const unsigned*)rects_xy, true, n, key_bits, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
+int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, int32_t id_width, uint32_t* keys_out, int32_t* index_out,
+                   void* ws, size_t ws_bytes, void* stream_) {
+  return sort_impl((const unsigned*)rects_xy, true, n, key_bits, id_width, keys_out, index_out, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream_) {

@@ -215,7 +215,7 @@ def pixel_key_bits(image_width, image_height):
     return max(1, (int(image_height) * 10000 + int(image_width)).bit_length())
 
 
-def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bits=None):
+def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bits=None, image_size=None):
     """Per-pixel exclusive transmittance (flag="cumprod") or exclusive prefix sum
     (flag="cumsum") of `anti_opacity`, returned in the ORIGINAL pair order.
 
@@ -225,10 +225,11 @@ def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bi
          way in, inclusive results scattered through it on the way out;
       3. drop `cutting_number` carry rows, compact the entries whose inclusive value is exactly 0 (:557-560, :575-578),
          then inclusive / self (:562) or inclusive - self (:564): ONE stable stream compaction in original order.
-    Returns [values, mask].  `key_bits` (keyword-only extension): `pixel_key_bits(width, height)`; None reads the key
-    range back once."""
+    Returns [values, mask].  Keyword-only extensions: `image_size=(width, height)` — what the Function holds as
+    image_width / image_height (gs_model.py:666); the sort then runs on compact pixel ids — or `key_bits`
+    (`pixel_key_bits(width, height)`); with neither the key range is read back once."""
     with torch.no_grad():
-        sorted_inv, index = _raster.sort_rects(rects, key_bits)
+        sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, anti_opacity, flag, cutting_number)
 
 
@@ -283,7 +284,7 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
         return _scan_boxes_compact(startpoint, endpoint, anti_opacity, image_width, image_height, flag)
 
 
-def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None):
+def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=None):
     """Per-pixel exclusive SUFFIX sum of `grad` in original pair order.
 
     reference: gs_model.py:716-722 (flip, _create_alpha_brend(flag="cumsum"), flip).
@@ -294,7 +295,7 @@ def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None):
     returned in ORIGINAL order (the reference leaves it flipped).
     """
     with torch.no_grad():
-        sorted_inv, index = _raster.sort_rects(rects, key_bits)
+        sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
 
 

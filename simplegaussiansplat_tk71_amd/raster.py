@@ -337,10 +337,12 @@ def rects_key_bits(rects):
     return max(1, int(mx).bit_length())
 
 
-def sort_rects(rects, key_bits=None):
+def sort_rects(rects, key_bits=None, image_size=None):
     """Stable sort of the reference's pixel keys straight from its rect list (gs_model.py:538-541, :546-547): returns
     (sorted_key int32[n], index int32[n]) = torch.sort(rects[:,1]*10000 + rects[:,0], stable=True) without ever writing
-    the unsorted key array.  `key_bits`: bits of the largest key ((H*10000+W).bit_length()); None = one read-back."""
+    the unsorted key array.  `image_size` = (width, height) with every x <= width, y <= height (the Function knows them,
+    gs_model.py:666): the passes run on compact pixel ids (21 bits, three passes of 7 at 1920x1080).  Else `key_bits`:
+    bits of the largest key ((H*10000+W).bit_length()); neither = one read-back of the key range."""
     r = _dev_tensor(rects, "rects", torch.int32, (2,))
     n = r.size(0)
     dev = r.device
@@ -348,13 +350,22 @@ def sort_rects(rects, key_bits=None):
     out_i = torch.empty(n, dtype=torch.int32, device=dev)
     if n == 0:
         return out_k, out_i
-    if key_bits is None:
+    id_width = 0
+    if image_size is not None:
+        w, h = int(image_size[0]), int(image_size[1])
+        _require(0 <= w < 10000 and h >= 0, "image_size: expected 0 <= width < 10000 and height >= 0")
+        bits = max(1, (h * (w + 1) + w).bit_length())
+        if bits <= 24:
+            id_width, key_bits = w + 1, bits
+        else:  # too large for the compact form: plain keys
+            key_bits = max(1, (h * 10000 + w).bit_length())
+    elif key_bits is None:
         key_bits = rects_key_bits(r)
     lib = _lib.load()
     with torch.cuda.device(dev):
         ws = torch.empty(lib.gcp_sort_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gcp_sort_rects(r.data_ptr(), n, int(key_bits), out_k.data_ptr(), out_i.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      _stream(dev)), "gcp_sort_rects")
+        _lib.check(lib.gcp_sort_rects(r.data_ptr(), n, int(key_bits), int(id_width), out_k.data_ptr(), out_i.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _stream(dev)), "gcp_sort_rects")
     return out_k, out_i
 
 

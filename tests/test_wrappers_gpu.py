@@ -22,8 +22,8 @@ def _parity(got, want, scale, what):
     assert bool((err <= bound).all()), f"{what}: max err {err.max().item():.3g}"
 
 
-@pytest.mark.parametrize("with_bits", [True, False])
-def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, with_bits):
+@pytest.mark.parametrize("how", ["image_size", "key_bits", "read_back"])
+def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, how):
     """BASELINE config 2 (1920x1080, 100k Gaussians, 1.65e7 pairs): masks and sort results bit-exact, values within
     1e-5 of the sequential CPU statement."""
     import cuda_kernel as ck
@@ -39,12 +39,13 @@ def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, with_bi
     anti[torch.randint(0, m, (m // 50,), device=device, generator=g)] = 0.0  # opaque pairs: everything behind them is dropped
     grad = torch.randn(m, device=device, generator=g)
     grad[torch.randint(0, m, (m // 7,), device=device, generator=g)] = 0.0
-    bits = ck.pixel_key_bits(sc["width"], sc["height"]) if with_bits else None
+    kw = {"image_size": {"image_size": (sc["width"], sc["height"])}, "key_bits": {"key_bits": ck.pixel_key_bits(sc["width"], sc["height"])},
+          "read_back": {}}[how]
 
-    sk, idx = raster.sort_rects(rects, bits)
+    sk, idx = raster.sort_rects(rects, **kw)
     rc, ac, gc_ = rects.cpu(), anti.cpu(), grad.cpu()
     for flag in ("cumprod", "cumsum"):
-        vals, mask = ck.create_alpha_brend(rects, anti, flag, key_bits=bits)
+        vals, mask = ck.create_alpha_brend(rects, anti, flag, **kw)
         w_vals, w_mask, w_sorted, w_index = ow.create_alpha_brend(rc, ac, flag)
         assert torch.equal(sk.cpu(), w_sorted.to(torch.int32)) and torch.equal(idx.cpu().long(), w_index)
         assert torch.equal(mask.cpu(), w_mask), flag
@@ -59,7 +60,7 @@ def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, with_bi
         else:
             _parity(b_vals, w_vals, w_vals.abs(), flag + " (boxes)")
     assert int((~w_mask).sum()) > 1000  # the compaction had something to drop
-    vals, mask = ck.grad_cumsum(rects, grad, key_bits=bits)
+    vals, mask = ck.grad_cumsum(rects, grad, **kw)
     w_vals, w_mask_flipped = ow.grad_cumsum(rc, gc_)
     assert torch.equal(mask.cpu(), w_mask_flipped.flip(0))  # ours in ORIGINAL order
     _parity(vals, w_vals, 4.0 + w_vals.abs(), "grad_cumsum")  # suffix sums of ~8 N(0,1) terms per pixel
@@ -112,6 +113,10 @@ def test_sort_rects_equals_torch_stable_sort_of_the_keys(device, n, wmax, hmax):
     for bits in (None, ck.pixel_key_bits(wmax, hmax), 31):
         got_k, got_i = raster.sort_rects(rects.to(device), bits)
         assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_i.cpu().long(), want_i), bits
+    # the image size given: compact pixel ids inside the passes (where they fit 24 bits), the reference's keys on the way out
+    for size in ((wmax, hmax), (min(wmax + 37, 9999), hmax + 5)):
+        got_k, got_i = raster.sort_rects(rects.to(device), image_size=size)
+        assert torch.equal(got_k.cpu(), want_k) and torch.equal(got_i.cpu().long(), want_i), size
     assert raster.rects_key_bits(rects.to(device)) == max(1, int(key.max()).bit_length())
 
 

@@ -22,4 +22,13 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/long_write -o p --output-forma
 echo "== Function kernels: stats, then SQ counters"
 rocprofv3 --kernel-trace --stats -d $OUT/fn_stats -o st --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > $OUT/fn_bench.txt 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --kernel-trace -d $OUT/fn_pmc -o p --output-format csv -- python3 $ROOT/tools/raster_bench.py --no-cameras > /dev/null 2>&1
+echo "== rows a5 / a6 (create_alpha_brend, grad_cumsum, and their boxes route): stats, then traffic"
+mkdir -p $OUT/wr_stats $OUT/wr_fetch $OUT/wr_write
+python3 $ROOT/tools/wrapper_bench.py cfg2 cfg3 --stages > $OUT/wr_bench.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/wr_stats -o st --output-format csv -- python3 $ROOT/tools/wrapper_bench.py cfg3 --profile --iters 4 > $OUT/wr_prof.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/wr_fetch -o p --output-format csv -- python3 $ROOT/tools/wrapper_bench.py cfg3 --profile --iters 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/wr_write -o p --output-format csv -- python3 $ROOT/tools/wrapper_bench.py cfg3 --profile --iters 2 > /dev/null 2>&1
+echo "== blend kernels: could two list entries share a visit?"
+python3 $ROOT/tools/blend_pairing_stats.py cfg3 > $OUT/pairing.txt 2>&1
+python3 $ROOT/tools/blend_pairing_stats.py cfg2 >> $OUT/pairing.txt 2>&1
 echo "== done"; ls $OUT

@@ -124,6 +124,7 @@ def main():
     print("\n".join(lines))
     long_groups(src, tag, out)
     function_kernels(src, tag, out)
+    wrappers(src, tag, out)
 
 
 def per_launch(dirname, counter, pick):
@@ -208,6 +209,66 @@ def function_kernels(src, tag, out):
     open(os.path.join(out, f"{tag}_function_kernels.md"), "w").write("\n".join(lines) + "\n")
     path = os.path.join(out, "pmc_function.json")
     json.dump({"cfg3": pj, "_source": f"{tag}: rocprofv3 --pmc (SQ counters) pass of tools/raster_bench.py"}, open(path, "w"), indent=1)
+    print("\n".join(lines))
+
+
+WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
+    ("k_sort_hist2<true>", "sort pass 0: histogram (reads the rects)", 8, "rects"),
+    ("k_sort_scatter2<true, true>", "sort pass 0: scatter (rects -> key + index)", 16, "rects"),
+    ("k_sort_hist2<false>", "sort passes 1, 2: histogram (per pass)", 4, "rects"),
+    ("k_sort_scatter2<false, false>", "sort passes 1, 2: scatter (per pass)", 16, "rects"),
+    ("gcp_scan_main<0, true, false, true>", "indexed scan, cumprod (gather + scan + un-sort)", 16, "rects"),
+    ("gcp_scan_main<3, true, false, true>", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
+    ("k_compact<true, false>", "compaction: count pass", 4, "both"),
+    ("k_compact<true, true>", "compaction: write pass (mask + kept values)", 13, "both"),
+    ("k_pairs_scan_boxes<0>", "boxes route: tile-list walk, cumprod", 8, "boxes"),
+    ("k_pairs_scan_boxes<2>", "boxes route: tile-list walk, suffix sum", 8, "boxes"),
+]
+
+
+def wrappers(src, tag, out):
+    """Rows a5 / a6: kernel table of `tools/wrapper_bench.py cfg3 --profile` with the FETCH / WRITE passes beside it."""
+    if not os.path.isdir(os.path.join(src, "wr_stats")):
+        return
+    trace = max(glob.glob(os.path.join(src, "wr_stats", "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(trace)))
+    m = json.loads([ln for ln in open(os.path.join(src, "wr_prof.txt")).read().splitlines() if ln.startswith("{")][-1])["pairs"]
+    pick = lambda k: next((label for frag, label, _, _ in WRAPPER_KERNELS if frag in k), None)  # noqa: E731
+    dur = collections.defaultdict(list)
+    other = collections.defaultdict(list)
+    for r in rows:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        lab = pick(r["Kernel_Name"])
+        (dur[lab] if lab else other[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]]).append(d)
+    fetch = {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "wr_fetch"), "FETCH_SIZE", pick).items()}
+    write = {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "wr_write"), "WRITE_SIZE", pick).items()}
+    lines = [f"# {tag}: rows a5 / a6 — create_alpha_brend / grad_cumsum (gs_model.py:544-566, :716-722) at the cfg3 scene, M = {m} pairs", "",
+             "`rocprofv3 --kernel-trace --stats` of `python3 tools/wrapper_bench.py cfg3 --profile` (create_alpha_brend(rects), "
+             "grad_cumsum(rects), create_alpha_brend_boxes, grad_cumsum_boxes, 4 times each) and separate `--pmc FETCH_SIZE` / `--pmc "
+             "WRITE_SIZE` passes of the same command.  HBM bytes = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950 "
+             "correction of the guide; FETCH_SIZE halves only wide streaming reads, so for the gather / scatter kernels the figure "
+             "is an upper bound).", "",
+             "| kernel | launches | avg us | algorithmic B / pair | algorithmic GB/s | frac of 8 TB/s | HBM bytes / launch (PMC) | traffic / algorithmic |",
+             "|---|---|---|---|---|---|---|---|"]
+    for frag, label, bpp, route in WRAPPER_KERNELS:
+        if label not in dur:
+            continue
+        avg = sum(dur[label]) / len(dur[label])
+        alg = bpp * m
+        hb = (2.0 * fetch[label] + write[label]) * 1024.0 if label in fetch and label in write else None
+        lines.append(f"| {label} | {len(dur[label])} | {avg:.1f} | {bpp} | {alg / avg / 1e3:.0f} | {alg / avg / 1e3 / 8000:.3f} | "
+                     f"{hb:.4g} | {hb / alg:.2f} |" if hb else f"| {label} | {len(dur[label])} | {avg:.1f} | {bpp} | {alg / avg / 1e3:.0f} | {alg / avg / 1e3 / 8000:.3f} | n/a | n/a |")
+    lines += ["", "Small kernels of the same calls (K-sized binning, prefix sums, follow-up launches):", "", "| kernel | launches | avg us |", "|---|---|---|"]
+    for k, v in sorted(other.items(), key=lambda kv: -sum(kv[1])):
+        if sum(v) / len(v) > 2.0 and ("k_" in k or "gcp_" in k):
+            lines.append(f"| {k} | {len(v)} | {sum(v) / len(v):.1f} |")
+    if os.path.exists(os.path.join(src, "wr_bench.txt")):
+        keep = [ln for ln in open(os.path.join(src, "wr_bench.txt")).read().splitlines() if ln.startswith("{")]
+        lines += ["", "Whole calls and stages, HIP events around the Python calls, no profiler (`tools/wrapper_bench.py cfg2 cfg3 --stages`):", "", "```", *keep, "```"]
+    if os.path.exists(os.path.join(src, "pairing.txt")):
+        keep = [ln for ln in open(os.path.join(src, "pairing.txt")).read().splitlines() if ln.startswith("{")]
+        open(os.path.join(out, f"{tag}_blend_pairing.jsonl"), "w").write("\n".join(keep) + "\n")
+    open(os.path.join(out, f"{tag}_wrappers.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 

@@ -45,6 +45,20 @@ def main():
         del argv[i:i + 2]
     args = [a for a in argv if not a.startswith("--")]
     stages = "--stages" in argv
+    if "--profile" in argv:  # only the four whole calls, `iters` times each: what tools/profile_round.sh runs under rocprofv3
+        dev = torch.device("cuda", 0)
+        for cfg in (args or ["cfg3"]):
+            sc, rects, anti, grad = scene_inputs(cfg, dev)
+            w, h = sc["width"], sc["height"]
+            bits = ck.pixel_key_bits(w, h)
+            for _ in range(iters):
+                ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h))
+                ck.grad_cumsum(rects, grad, image_size=(w, h))
+                ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod")
+                ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h)
+            torch.cuda.synchronize()
+            print(json.dumps({"workload": cfg, "pairs": rects.size(0), "iters": iters}))
+        return
     dev = torch.device("cuda", 0)
     for cfg in (args or ["cfg2", "cfg3"]):
         sc, rects, anti, grad = scene_inputs(cfg, dev)
@@ -53,17 +67,19 @@ def main():
         out = {"workload": cfg, "pairs": m, "gaussians": int(sc["start"].size(0))}
         bits = ck.pixel_key_bits(w, h)
         out["key_bits"] = bits
-        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits), iters)
-        out["create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", key_bits=bits), iters)
-        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, key_bits=bits), iters)
+        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h)), iters)
+        out["create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", image_size=(w, h)), iters)
+        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h)), iters)
+        out["create_alpha_brend_key_bits_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits), iters)
         out["create_alpha_brend_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)
         out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
         out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
         if stages:
             import grouped_cumprod as gc
 
-            st = {"sort_rects_ms": timeit(lambda: raster.sort_rects(rects, bits), iters)}
-            sk, idx = raster.sort_rects(rects, bits)
+            st = {"sort_rects_ms": timeit(lambda: raster.sort_rects(rects, image_size=(w, h)), iters),
+                  "sort_rects_key_bits_ms": timeit(lambda: raster.sort_rects(rects, bits), iters)}
+            sk, idx = raster.sort_rects(rects, image_size=(w, h))
             incl = torch.empty_like(anti)
             st["indexed_scan_ms"] = timeit(lambda: gc.grouped_cumprod_forward_indexed(anti, sk, idx, incl), iters)
             st["indexed_reverse_scan_ms"] = timeit(lambda: gc.grouped_cumsum_reverse_indexed(grad, sk, idx, incl), iters)

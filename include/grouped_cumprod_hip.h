@@ -17,13 +17,15 @@
  *     ADJACENT keys — keys need not be globally sorted
  *     (thrust::equal_to<int>, grouped_cumprod_forward.cu:21);
  *   - outputs are caller-allocated and overwritten; nothing is retained by the
- *     library.  An output array must NOT overlap any input array of the same
- *     call (no in-place scan: blocks re-read raw inputs of the neighbouring
- *     tile while that tile's block is already storing) — overlapping ranges
- *     return GCP_ERR_INVALID_ARGUMENT.  (The reference's
- *     thrust::inclusive_scan_by_key tolerates y == x,
- *     grouped_cumprod_forward.cu:17-23; none of its callers uses that:
- *     gs_model.py:549 and cuda_test.py:22,25 allocate fresh outputs.)
+ *     library.  The forward scans (gcp_cumprod_forward, gcp_cumsum_forward,
+ *     gcp_cumsum_reverse) may run EXACTLY in place, y == x, as the reference's
+ *     thrust::inclusive_scan_by_key may (grouped_cumprod_forward.cu:17-23): the
+ *     library then takes every carry from its tile descriptors instead of
+ *     re-reading the neighbouring tile's inputs (0.5 instead of 0.7 of the HBM
+ *     roof).  Any other overlap of an output with an input of the same call —
+ *     shifted views, the backward, the carry and indexed forms — returns
+ *     GCP_ERR_INVALID_ARGUMENT (blocks re-read raw inputs of the neighbouring
+ *     tile while that tile's block is already storing).
  *   - launches are asynchronous on `stream`; no host synchronisation, no
  *     allocation when a workspace is supplied (graph-capturable);
  *   - every function returns GCP_OK (0) or a GCP_ERR_* code; n == 0 is a no-op;

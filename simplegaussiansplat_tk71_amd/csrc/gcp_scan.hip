@@ -146,6 +146,7 @@ struct ScanArgs {
   i64 lvl_off[kLevels + 1];       // first entry of every level of the radix-64 block tree; [kLevels] = entries in all
   unsigned* hdr;      // workspace header (kHdr*)
   int xcd_remap;
+  int inplace;        // out IS in0 (the reference's Thrust scans are legal in place): no tile may re-read another tile's inputs
   long long patience; // longest wait for a missing descriptor, in 100 MHz ticks; < 0: no descriptor walk at all
 };
 
@@ -373,7 +374,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   if (nb_exists) nbk = a.key[pn];
 
   // look-back chunk 0 (wave 0 only): issued now so its latency overlaps
-  const bool do_lb = !FIXUP && (w == 0) && (lt > 0);
+  const bool do_lb = !FIXUP && !a.inplace && (w == 0) && (lt > 0);
   float4_t lbv = {id, id, id, id};
   int4_t lbk = {0, 0, 0, 0};
   i64 lbp = 0;
@@ -547,6 +548,12 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         if (done && !first_is_head) tc = M::op(a.carry[k0], tc);
       }
     }
+    if (!FIXUP && a.inplace && lt > 0) {
+      // in place the neighbouring tile's inputs may already be overwritten by its results: no raw look-back at all — a tile
+      // that continues a group takes its carry from the descriptor tree (aggregates only, computed before any store)
+      const int k0 = __builtin_amdgcn_readfirstlane(kk[0].x);
+      if (nb_exists && nbk == k0) unresolved = 1;
+    }
     // [kWaves]: the raw window was exhausted (never rewritten: every wave branches on it after the barrier);
     // [kWaves + 1]: the carry is still unknown (cleared by the descriptor walk when it succeeds)
     if (lane == 0) { s_tc[0] = tc; s_wf[kWaves] = unresolved; s_wf[kWaves + 1] = unresolved; }
@@ -696,7 +703,9 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       y.w = y.w / (xp[r].w != 0.0f ? xp[r].w : 1e-8f);
     }
     y = to_scan_order<REV>(y);  // involution: back to memory order
-    if constexpr (INDEXED) {  // un-sort: through the permutation (gs_model.py:555 `output[torch.argsort(index)]`)
+    // a tile whose carry is still unknown stores nothing: the follow-up kernel re-runs it from its (intact) inputs
+    if (unresolved) {
+    } else if constexpr (INDEXED) {  // un-sort: through the permutation (gs_model.py:555 `output[torch.argsort(index)]`)
       if (FULL || p0[r] + 0 < n) a.out[ix[r].x] = y.x;
       if (FULL || p0[r] + 1 < n) a.out[ix[r].y] = y.y;
       if (FULL || p0[r] + 2 < n) a.out[ix[r].z] = y.z;
@@ -989,9 +998,12 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   if (Mode<MODE>::kBwd && (!in1 || !in2)) return GCP_ERR_INVALID_ARGUMENT;
   // No aliasing: the look-back re-reads the neighbouring tile's RAW inputs while that tile's block may already be
   // storing its outputs, so an output range that shares bytes with an input range races between blocks.
+  // Exactly in place (out == x) is served — the reference's thrust::inclusive_scan_by_key allows it
+  // (grouped_cumprod_forward.cu:17-23) — by a mode that never re-reads another tile's inputs; any other overlap is refused.
+  const bool inplace = !Mode<MODE>::kBwd && !index && !carry && (const void*)out == (const void*)in0;
   {
     const uintptr_t o0 = (uintptr_t)out, o1 = o0 + (uintptr_t)n * 4u;
-    const void* ins[5] = {in0, in1, in2, key, index};
+    const void* ins[5] = {inplace ? nullptr : in0, in1, in2, key, index};
     for (const void* q : ins) {
       const uintptr_t q0 = (uintptr_t)q;
       if (q && o0 < q0 + (uintptr_t)n * 4u && q0 < o1) return GCP_ERR_INVALID_ARGUMENT;
@@ -1010,7 +1022,7 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   char* p = (char*)ws;
   ScanArgs a;
   a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry; a.index = index;
-  a.n = n; a.ntiles = ntiles;
+  a.n = n; a.ntiles = ntiles; a.inplace = inplace ? 1 : 0;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
   a.desc_sets = (unsigned long long*)p;
   ws_levels(n, a.lvl_off);

@@ -173,10 +173,11 @@ def test_argument_errors(device):
         gc.grouped_cumprod_forward(x[::2], k[::2], x[::2])  # non-contiguous
 
 
-def test_outputs_that_alias_inputs_are_rejected(device):
-    """Thrust's inclusive_scan_by_key is legal in place (grouped_cumprod_forward.cu:17-23); this library's blocks
-    re-read the neighbouring tile's raw inputs, so an output sharing bytes with an input is refused — by the Python
-    module (RuntimeError) and by the C ABI itself (GCP_ERR_INVALID_ARGUMENT) — instead of racing."""
+def test_outputs_that_overlap_inputs_are_rejected_unless_exactly_in_place(device):
+    """Thrust's inclusive_scan_by_key is legal in place (grouped_cumprod_forward.cu:17-23) and so are the three forward
+    scans here (out is x: a mode that never re-reads another tile's inputs).  Every other overlap — shifted views, the
+    backward's output on any of its inputs, the carry variants — is refused by the Python module (RuntimeError) and by
+    the C ABI itself (GCP_ERR_INVALID_ARGUMENT) instead of racing."""
     import ctypes
 
     from simplegaussiansplat_tk71_amd import _lib
@@ -188,9 +189,9 @@ def test_outputs_that_alias_inputs_are_rejected(device):
     big = torch.rand(2 * n, device=device)
     for fn in (gc.grouped_cumprod_forward, gc.grouped_cumsum_forward, gc.grouped_cumsum_reverse):
         with pytest.raises(RuntimeError, match="overlaps"):
-            fn(x, k, x)                                  # y is x
-        with pytest.raises(RuntimeError, match="overlaps"):
             fn(big[:n], k, big[n // 2 : n // 2 + n])     # partial overlap of two views
+        with pytest.raises(RuntimeError, match="overlaps"):
+            fn(big[:n], k.view(torch.float32).view(torch.int32), k.view(torch.float32))  # the output on the keys
         fn(big[:n], k, big[n:])                          # adjacent, disjoint views are fine
     il = torch.tensor([n], device=device, dtype=torch.int32)
     y = torch.empty_like(x)
@@ -201,11 +202,49 @@ def test_outputs_that_alias_inputs_are_rejected(device):
         gc.grouped_cumprod_forward_carry(x, k, torch.ones(1, device=device), x)
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.gcp_cumprod_forward(x.data_ptr(), k.data_ptr(), x.data_ptr(), n, None, 0, st) == 1  # GCP_ERR_INVALID_ARGUMENT
+    assert lib.gcp_cumprod_forward(big.data_ptr(), k.data_ptr(), big.data_ptr() + 4 * 100, n, None, 0, st) == 1  # GCP_ERR_INVALID_ARGUMENT
     assert lib.gcp_cumprod_backward(x.data_ptr(), y.data_ptr(), y.data_ptr(), k.data_ptr(), y.data_ptr(), il.data_ptr(), n, 1,
                                     None, 0, st) == 1
     assert ctypes.c_int(lib.gcp_cumprod_forward(x.data_ptr(), k.data_ptr(), y.data_ptr(), n, None, 0, st)).value == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dist", ["poisson8", "geo80", "runs3000", "runs9000", "one_run", "mixed", "all1"])
+@pytest.mark.parametrize("n", [5, 4096, 4097, 100003, 1_200_011])
+def test_forward_scans_exactly_in_place(device, n, dist):
+    """out is x (reference: thrust::inclusive_scan_by_key with the output iterator on the input, legal;
+    grouped_cumprod_forward.cu:17-23): the same values as the CPU statement, for every wait setting of the descriptor
+    tree (in place ALL carries come from it), reproducibly; through the Python module and through the C ABI."""
+    gc, co = _mods()
+    from simplegaussiansplat_tk71_amd import _lib
+
+    key = make_keys(n, dist, seed=n % 89)
+    kd = key.to(device)
+    x = make_values(n, 7, "near1" if dist in ("one_run", "runs9000", "runs3000") else "alpha")
+    xs = make_values(n, 8, "normal")
+    want = {"cumprod": (co.cumprod_forward(x, key), co.cumprod_forward_f64(x, key)),
+            "cumsum": (co.cumsum_forward(xs, key), co.cumsum_forward_f64(xs.abs(), key)),
+            "reverse": (co.cumsum_reverse(xs, key), co.cumsum_forward_f64(xs.abs().flip(0).contiguous(), key.flip(0).contiguous()).flip(0))}
+    first = {}
+    try:
+        for wait in (200, 0, -1):
+            gc.set_lookback_wait_us(wait)
+            for name, fn, src in (("cumprod", gc.grouped_cumprod_forward, x), ("cumsum", gc.grouped_cumsum_forward, xs),
+                                  ("reverse", gc.grouped_cumsum_reverse, xs)):
+                buf = src.to(device).clone()
+                fn(buf, kd, buf)
+                assert_parity(buf, want[name][0], want[name][1], f"in place {name} {dist} wait={wait}")
+                if name in first:
+                    assert torch.equal(buf, first[name]), (name, wait)  # the same bits whatever the wait
+                first[name] = buf
+    finally:
+        gc.set_lookback_wait_us(200)
+    lib = _lib.load()
+    buf = x.to(device).clone()
+    ws = torch.zeros(lib.gcp_workspace_bytes(n), dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.gcp_cumprod_forward(buf.data_ptr(), kd.data_ptr(), buf.data_ptr(), n, ws.data_ptr(), ws.numel(), st) == 0
+    assert torch.equal(buf, first["cumprod"])
 
 
 @pytest.fixture(params=[200, 0, -1], ids=["walk", "walk-no-wait", "two-pass"])

@@ -985,13 +985,19 @@ __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __r
 constexpr int kWalkStage = 64;  // list entries staged per round: one hit word per wave
 template <int MODE>  // 0 cumprod, 1 cumsum, 2 reverse cumsum
 __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
-                                                          const float* __restrict__ x, float* __restrict__ out) {
+                                                          const float* __restrict__ x, float* __restrict__ out, int n_tiles,
+                                                          int xcd_remap) {
   __shared__ int4 s_box[kWalkStage];   // x0, y0, x1, y1 (clamped to the image)
   __shared__ int s_off[kWalkStage];    // first Gaussian-major pair of the entry's Gaussian
   __shared__ unsigned long long s_hits[4];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tile = blockIdx.x;
+  // A box is one contiguous run of the pair arrays (row-major, uitility.py:336-366) but lies across up to 2 x 2 tiles: with
+  // blocks dealt round-robin over the XCDs its pieces would be written from different L2s and reach memory as partial
+  // lines (measured: 2.6x the algorithmic bytes).  XCD x therefore takes the x-th contiguous eighth of the tiles
+  // (row-major = a band of tile rows): horizontal and, but for the band edges, vertical neighbours share an L2.
+  const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);
+  if (tile < 0) return;
   const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
   const int px = tile_x0 + (lane & 15);
   const int py = tile_y0 + w * 4 + (lane >> 4);
@@ -1614,10 +1620,12 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
   if (n_gauss == 0) return GCP_OK;
   if (!start_xy || !end_xy || !tile_list || !box_off || !x || !inclusive || x == inclusive) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
-  const dim3 grid((unsigned)(tg.tx * tg.ty)), block(256);
-  if (mode == 0) hipLaunchKernelGGL((k_pairs_scan_boxes<0>), grid, block, 0, stream, a, box_off, x, inclusive);
-  else if (mode == 1) hipLaunchKernelGGL((k_pairs_scan_boxes<1>), grid, block, 0, stream, a, box_off, x, inclusive);
-  else hipLaunchKernelGGL((k_pairs_scan_boxes<2>), grid, block, 0, stream, a, box_off, x, inclusive);
+  static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 1; }();
+  const int n_tiles = tg.tx * tg.ty;
+  const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);
+  if (mode == 0) hipLaunchKernelGGL((k_pairs_scan_boxes<0>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
+  else if (mode == 1) hipLaunchKernelGGL((k_pairs_scan_boxes<1>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
+  else hipLaunchKernelGGL((k_pairs_scan_boxes<2>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

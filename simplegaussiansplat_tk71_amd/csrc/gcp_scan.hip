@@ -277,12 +277,15 @@ template <bool REV> __device__ __forceinline__ int4_t to_scan_order(int4_t v) {
 // same time, which is what keeps the descriptor look-back's waits short.  Performance only: nothing depends on where
 // or when a block runs.
 __device__ __forceinline__ i64 logical_tile(i64 b, i64 ntiles, int xcd_remap) {
+  // xcd_remap = log2 of the run length + 1 (0: dispatch order); kXcdChunk = 32 for the plain scans.  The INDEXED scans
+  // take longer runs (128 tiles): their gathers and scatters go to the pairs' ORIGINAL positions, where the pairs of
+  // vertically neighbouring pixels — a few dozen tiles apart in sorted order — share cache lines.
   if (!xcd_remap) return b;
-  constexpr i64 G = 8 * kXcdChunk;
-  const i64 full = (ntiles / G) * G;
+  const int lg = xcd_remap - 1 + 3;  // log2 of the group of 8 runs
+  const i64 full = (ntiles >> lg) << lg;
   if (b >= full) return b;  // the last, partial group keeps dispatch order
-  const i64 g = b / G, r = b - g * G;
-  return g * G + (r & 7) * kXcdChunk + (r >> 3);
+  const i64 g = b >> lg, r = b & (((i64)1 << lg) - 1);
+  return (g << lg) + ((r & 7) << (lg - 3)) + (r >> 3);
 }
 
 __device__ __forceinline__ unsigned long long pack_desc(float agg, unsigned flags, int first_head) {
@@ -1027,7 +1030,9 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   a.desc_sets = (unsigned long long*)p;
   ws_levels(n, a.lvl_off);
   static const int xcd_remap = env_int("GCP_XCD_REMAP", GCP_XCD_REMAP_DEFAULT);
-  a.xcd_remap = xcd_remap;
+  static const int chunk_lg = [] { int l = 0; while ((1 << l) < kXcdChunk) ++l; return l; }();
+  static const int chunk_lg_indexed = env_int("GCP_XCD_CHUNK_INDEXED_LOG2", 7);
+  a.xcd_remap = xcd_remap ? 1 + (index ? chunk_lg_indexed : chunk_lg) : 0;
   long long us = g_patience_us.load(std::memory_order_relaxed);
   if (us == -2) { us = env_int("GCP_DESC_WAIT_US", GCP_DESC_WAIT_US); g_patience_us.store(us, std::memory_order_relaxed); }
   a.patience = us < 0 ? -1 : us * 100;  // wall_clock64() counts at 100 MHz

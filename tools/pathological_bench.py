@@ -51,6 +51,15 @@ def main():
             print(f"{name:32s} fwd {tf*1e3:8.1f} us ({12*n/tf/1e6:6.0f} GB/s = {12*n/tf/1e6/80:4.1f} %)  bwd {tb*1e3:8.1f} us "
                   f"({20*n/tb/1e6:6.0f} GB/s = {20*n/tb/1e6/80:4.1f} %)  tiles: walked {lb}, left to the follow-up kernel {fb}", flush=True)
     gc.set_lookback_wait_us(200)
+    if not only or any("in place" in o for o in only):
+        # exactly in place (out is x): every continuing tile takes its carry from the descriptor tree
+        key = cases["groups of 80 (reference point)"]
+        xs = torch.randn(n, device=dev, generator=g)
+        buf = xs.clone()
+        t_in = timeit(lambda: gc.grouped_cumsum_forward(buf, key, buf))   # (a running sum of running sums: values irrelevant here)
+        t_out = timeit(lambda: gc.grouped_cumsum_forward(xs, key, y))
+        print(f"--- in place\ngroups of 80, cumsum: in place {t_in*1e3:8.1f} us ({12*n/t_in/1e6/80:4.1f} %)   out of place {t_out*1e3:8.1f} us "
+              f"({12*n/t_out/1e6/80:4.1f} %)", flush=True)
 
 
 if __name__ == "__main__":

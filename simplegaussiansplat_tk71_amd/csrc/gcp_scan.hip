@@ -146,7 +146,6 @@ struct ScanArgs {
   i64 lvl_off[kLevels + 1];       // first entry of every level of the radix-64 block tree; [kLevels] = entries in all
   unsigned* hdr;      // workspace header (kHdr*)
   int xcd_remap;
-  int inplace;        // out IS in0 (the reference's Thrust scans are legal in place): no tile may re-read another tile's inputs
   long long patience; // longest wait for a missing descriptor, in 100 MHz ticks; < 0: no descriptor walk at all
 };
 
@@ -297,7 +296,7 @@ __device__ __forceinline__ unsigned long long pack_desc(float agg, unsigned flag
 // ----------------------------------------------------------------------------
 // FIXUP: the follow-up kernel re-runs a tile whose wait for the descriptor tree ran out, with the carry `fix_carry` it
 // took from the (completed) tree: same code, same association, so the tile gets the bits it would have got in time.
-template <int MODE, bool ALIGNED, bool FULL, bool CARRY, bool FIXUP = false, bool INDEXED = false>
+template <int MODE, bool ALIGNED, bool FULL, bool CARRY, bool FIXUP = false, bool INDEXED = false, bool INPLACE = false>
 __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float* s_wv, int* s_wf,
                                           float* s_tc, int* s_fh, const float fix_carry = 0.0f) {
   typedef Mode<MODE> MD;
@@ -377,7 +376,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
   if (nb_exists) nbk = a.key[pn];
 
   // look-back chunk 0 (wave 0 only): issued now so its latency overlaps
-  const bool do_lb = !FIXUP && !a.inplace && (w == 0) && (lt > 0);
+  const bool do_lb = !FIXUP && !INPLACE && (w == 0) && (lt > 0);  // (in place: see below)
   float4_t lbv = {id, id, id, id};
   int4_t lbk = {0, 0, 0, 0};
   i64 lbp = 0;
@@ -551,7 +550,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         if (done && !first_is_head) tc = M::op(a.carry[k0], tc);
       }
     }
-    if (!FIXUP && a.inplace && lt > 0) {
+    if (!FIXUP && INPLACE && lt > 0) {
       // in place the neighbouring tile's inputs may already be overwritten by its results: no raw look-back at all — a tile
       // that continues a group takes its carry from the descriptor tree (aggregates only, computed before any store)
       const int k0 = __builtin_amdgcn_readfirstlane(kk[0].x);
@@ -690,6 +689,11 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
         __hip_atomic_store(entry(lvl, lt >> (6 * lvl)), pack_desc(agg, 0u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  // in place a tile whose carry is still unknown must not store: the follow-up kernel re-runs it from its intact inputs
+  // (out of place the re-run simply overwrites what is stored here)
+  if constexpr (INPLACE) {
+    if (__builtin_amdgcn_readfirstlane(unresolved)) return;
+  }
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
     const float e = ((lanes_open >> r) & 1u) ? M::op(R, eloc[r]) : eloc[r];
@@ -706,9 +710,7 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
       y.w = y.w / (xp[r].w != 0.0f ? xp[r].w : 1e-8f);
     }
     y = to_scan_order<REV>(y);  // involution: back to memory order
-    // a tile whose carry is still unknown stores nothing: the follow-up kernel re-runs it from its (intact) inputs
-    if (unresolved) {
-    } else if constexpr (INDEXED) {  // un-sort: through the permutation (gs_model.py:555 `output[torch.argsort(index)]`)
+    if constexpr (INDEXED) {  // un-sort: through the permutation (gs_model.py:555 `output[torch.argsort(index)]`)
       if (FULL || p0[r] + 0 < n) a.out[ix[r].x] = y.x;
       if (FULL || p0[r] + 1 < n) a.out[ix[r].y] = y.y;
       if (FULL || p0[r] + 2 < n) a.out[ix[r].z] = y.z;
@@ -728,8 +730,8 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
 
 // Forward modes: six blocks per CU (<= 80 VGPRs), which the rare descriptor walk must not cost; the reverse modes are
 // left to the register allocator (the backward holds three arrays per element and runs at three blocks per CU).
-template <int MODE, bool ALIGNED, bool CARRY, bool INDEXED = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((Mode<MODE>::kRev || INDEXED) ? 1 : 6, (Mode<MODE>::kRev || INDEXED) ? 8 : 6)))
+template <int MODE, bool ALIGNED, bool CARRY, bool INDEXED = false, bool INPLACE = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((Mode<MODE>::kRev || INDEXED || INPLACE) ? 1 : 6, (Mode<MODE>::kRev || INDEXED || INPLACE) ? 8 : 6)))
 void gcp_scan_main(const ScanArgs a) {
   __shared__ float s_wv[kWaves];
   __shared__ int s_wf[kWaves + 2];
@@ -737,8 +739,8 @@ void gcp_scan_main(const ScanArgs a) {
   __shared__ int s_fh[kWaves];
   const i64 lt = logical_tile((i64)blockIdx.x, a.ntiles, a.xcd_remap);
   const i64 pt = Mode<MODE>::kRev ? (a.ntiles - 1 - lt) : lt;
-  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true, CARRY, false, INDEXED>(a, lt, s_wv, s_wf, s_tc, s_fh);
-  else scan_tile<MODE, ALIGNED, false, CARRY, false, INDEXED>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  if ((pt + 1) * (i64)kTile <= a.n) scan_tile<MODE, ALIGNED, true, CARRY, false, INDEXED, INPLACE>(a, lt, s_wv, s_wf, s_tc, s_fh);
+  else scan_tile<MODE, ALIGNED, false, CARRY, false, INDEXED, INPLACE>(a, lt, s_wv, s_wf, s_tc, s_fh);
 }
 
 // ----------------------------------------------------------------------------
@@ -1025,7 +1027,7 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
   char* p = (char*)ws;
   ScanArgs a;
   a.in0 = in0; a.in1 = in1; a.in2 = in2; a.key = key; a.out = out; a.carry = carry; a.index = index;
-  a.n = n; a.ntiles = ntiles; a.inplace = inplace ? 1 : 0;
+  a.n = n; a.ntiles = ntiles;
   a.hdr = (unsigned*)p; p += kWsHeaderBytes;
   a.desc_sets = (unsigned long long*)p;
   ws_levels(n, a.lvl_off);
@@ -1047,6 +1049,9 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
     if (carry || index) return GCP_ERR_INVALID_ARGUMENT;
     if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false>), grid, block, 0, stream, a);
+  } else if (inplace) {  // out IS in0 (legal for the reference's Thrust scans): no tile may re-read another tile's inputs
+    if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gcp_scan_main<MODE, false, false, false, true>), grid, block, 0, stream, a);
   } else if (index) {
     if (carry) return GCP_ERR_INVALID_ARGUMENT;
     if (aligned) hipLaunchKernelGGL((gcp_scan_main<MODE, true, false, true>), grid, block, 0, stream, a);

@@ -124,3 +124,26 @@ def test_raster_rejects_cpu_tensors():
     z = torch.zeros(3, 2, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="no CPU path"):
         raster.bin_tiles(z, z, 16, 16)
+
+
+def test_streaming_scan_kernels_hold_their_registers_without_scratch(tmp_path):
+    """The forward scans are pinned to six waves per SIMD (80 VGPRs).  A change that pushes the tile routine over that
+    limit is spilled to scratch SILENTLY: the kernel still passes every test and loses a fifth of its write bandwidth
+    to spill traffic (round 3: +19 % WRITE_SIZE on the forward scan).  Compile the device code and read the
+    register report of every gcp_scan_main instantiation."""
+    import re
+    import subprocess
+
+    from simplegaussiansplat_tk71_amd import _build
+
+    src = [s for s in _build.SRCS if s.endswith("gcp_scan.hip")][0]
+    out = tmp_path / "scan.s"
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    res = subprocess.run([_build.find_hipcc(), *flags, "-I", _build.INCLUDE, "-S", "--cuda-device-only", "-o", str(out), src],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S*gcp_scan_main\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert len(kernels) >= 16
+    bad = [(k, scratch, spills) for k, scratch, spills in kernels if int(scratch) or int(spills)]
+    assert not bad, bad

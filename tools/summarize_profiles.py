@@ -28,13 +28,17 @@ def short(kernel):
     return None
 
 
-def pmc(dirname, counter):
+def pmc(dirname, counter, blocks=None):
+    """kernel -> mean of `counter` over the launches of `blocks` workgroups (None: all sizes)."""
     acc = collections.defaultdict(list)
     files = sorted(glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in files[-1:]:  # gpurun MERGES into gpurun_out/: only the newest run counts
         for r in csv.DictReader(open(f)):
             s = short(r["Kernel_Name"])
             if s and r["Counter_Name"] == counter:
+                if blocks is not None and s in ("cumprod_fwd", "cumprod_bwd", "cumsum_fwd", "cumsum_rev") and \
+                        abs(int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) - blocks) > 3:
+                    continue  # the same kernel on another workload of the same command (cfg2 block, wrappers, ...)
                 acc[s].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
@@ -74,12 +78,13 @@ def main():
     if os.path.exists(os.path.join(src, "bench_plain.json")):
         plain = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
     m = bench["config"]["pairs_per_gpu"]
-    fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    hb_blocks = (m + 4095) // 4096
+    fetch, write = pmc(os.path.join(src, "pmc_fetch"), "FETCH_SIZE", hb_blocks), pmc(os.path.join(src, "pmc_write"), "WRITE_SIZE", hb_blocks)
     traffic = {}
     lines = [f"# {tag}: rocprofv3 summary of `python3 bench.py` (cfg3, M = {m} pairs = {(m + 4095) // 4096} tiles)", "",
              "Rows are aggregated from the kernel trace per (kernel, grid size): the headline's timed region is the "
              f"{(m + 4095) // 4096}-tile launches of cumprod_fwd / cumprod_bwd; the other sizes of the same kernels belong to the "
-             "`unclipped` and `sharded_frames` blocks of the same command (rocprofv3's own --stats rows, which average over all of "
+             "`unclipped`, `cfg2`, `wrapper_level` and `sharded_frames` blocks of the same command (rocprofv3's own --stats rows, which average over all of "
              f"them, are in {tag}_kernel_stats_raw.csv).  PMC traffic is from the separate --pmc passes, averaged over the launches "
              "of those passes (GCP_BENCH_NO_SHARDED=1: the timed workload and its unclipped twin, same size within 0.01 %).", "",
              "| kernel | calls | avg us (rocprof) | algorithmic B/launch | algorithmic GB/s | FETCH_SIZE KiB (raw) | "
@@ -90,6 +95,8 @@ def main():
     headline_blocks = (m + tile - 1) // tile
     for r in ours:
         s = short(r["Name"])
+        if s is None:
+            continue  # kernels of the wrapper / Function / caller blocks of the same command: <tag>_wrappers.md, <tag>_function_kernels.md
         avg_us = float(r["AverageNs"]) / 1e3
         if s in per and r["Blocks"] != headline_blocks:
             lines.append(f"| {s} ({r['Blocks']} tiles: another workload of the same run) | {r['Calls']} | {avg_us:.1f} | - | "

@@ -224,8 +224,8 @@ WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
     ("k_sort_scatter2<true, true>", "sort pass 0: scatter (rects -> key + index)", 16, "rects"),
     ("k_sort_hist2<false>", "sort passes 1, 2: histogram (per pass)", 4, "rects"),
     ("k_sort_scatter2<false, false>", "sort passes 1, 2: scatter (per pass)", 16, "rects"),
-    ("gcp_scan_main<0, true, false, true>", "indexed scan, cumprod (gather + scan + un-sort)", 16, "rects"),
-    ("gcp_scan_main<3, true, false, true>", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
+    ("gcp_scan_main<0, true, false, true", "indexed scan, cumprod (gather + scan + un-sort)", 16, "rects"),
+    ("gcp_scan_main<3, true, false, true", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
     ("k_compact<true, false>", "compaction: count pass", 4, "both"),
     ("k_compact<true, true>", "compaction: write pass (mask + kept values)", 13, "both"),
     ("k_pairs_scan_boxes<0>", "boxes route: tile-list walk, cumprod", 8, "boxes"),

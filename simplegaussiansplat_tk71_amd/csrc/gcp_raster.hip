@@ -1562,8 +1562,9 @@ int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, int32_t
 int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || !out_dev) return GCP_ERR_INVALID_ARGUMENT;
-  const int init[2] = {0, 0x7fffffff};
-  GCP_HIP(hipMemcpyAsync(out_dev, init, sizeof(init), hipMemcpyHostToDevice, stream));
+  // (device-side fills: an asynchronous copy from this function's stack could outlive it)
+  GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)out_dev, 0, 1, stream));
+  GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(out_dev + 1), 0x7fffffff, 1, stream));
   if (n == 0) return GCP_OK;
   if (!rects_xy) return GCP_ERR_INVALID_ARGUMENT;
   i64 blocks = (n + 4095) / 4096;

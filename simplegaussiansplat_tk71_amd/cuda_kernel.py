@@ -275,9 +275,11 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
     `_create_rects(startpoint, endpoint)` feeds :607).  Nothing M-sized is sorted: the Gaussians are binned into 16x16
     tiles (K ~ 3 entries per Gaussian) and every pixel walks its tile's depth-ordered list, reading and writing each
     pair at its Gaussian-major position (raster.scan_boxes), then the same stream compaction.  `anti_opacity` is in the
-    reference's Gaussian-major rect order; returns the same [values, mask] as `create_alpha_brend(rects, ...)` — masks
-    identical, values scanned strictly in depth order (the association of the CPU path) instead of the tree order of the
-    flat scan, i.e. equal to it within fp32 round-off."""
+    reference's Gaussian-major rect order; returns the same [values, mask] as `create_alpha_brend(rects, ...)`, every
+    pixel scanned strictly in depth order (the association of the CPU path) instead of the tree order of the flat scan:
+    values equal within fp32 round-off; the mask (inclusive value != 0, gs_model.py:560) equal except where a value is
+    exactly 0 in one summation order only — signed sums that cancel, products at the edge of underflow: a handful among
+    1.65e8 pairs, as between the reference's CPU and GPU runs."""
     if flag not in ("cumprod", "cumsum"):
         raise ValueError(flag)
     with torch.no_grad():
@@ -301,7 +303,7 @@ def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=N
 
 def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
     """`grad_cumsum` (gs_model.py:716-722) from the boxes: the tile lists walked back to front; same [values, mask] as
-    `grad_cumsum(rects, grad)` (masks identical, values within fp32 round-off: sequential association)."""
+    `grad_cumsum(rects, grad)` (values within fp32 round-off, masks as explained at `create_alpha_brend_boxes`)."""
     with torch.no_grad():
         return _scan_boxes_compact(startpoint, endpoint, grad, image_width, image_height, "cumsum_reverse")
 

@@ -249,5 +249,17 @@ def test_wrappers_full_size_cfg3_scene_properties(device):
     del v_sort, v_box, k_sort, k_box
     s_sort, ks = ck.grad_cumsum(rects, grad, image_size=(w, h))
     s_box, kb = ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h)
-    assert torch.equal(ks, kb)
-    torch.testing.assert_close(s_sort, s_box, atol=2e-4, rtol=1e-5)  # suffix sums of up to a few thousand N(0,1) terms
+    # The mask keeps the pairs whose INCLUSIVE suffix sum is not exactly 0 (gs_model.py:560).  For signed fp32 terms that is
+    # a property of the summation order: among 1.65e8 sums a handful cancel to exactly 0 in the tree order of the flat scan
+    # and to 1e-8 in the sequential order of the walk, or the other way round (the reference's own mask moves
+    # with Thrust's association in the same way).  Everything else must agree.
+    differ = ks != kb
+    assert int(differ.sum()) <= 64, int(differ.sum())
+    full_s = torch.zeros(m, device=device)
+    full_b = torch.zeros(m, device=device)
+    full_s[ks] = s_sort
+    full_b[kb] = s_box
+    both = ks & kb
+    torch.testing.assert_close(full_s[both], full_b[both], atol=2e-4, rtol=1e-5)  # suffix sums of up to a few thousand N(0,1) terms
+    if bool(differ.any()):  # where they differ, the kept value is the term itself up to round-off: the rest of the sum is ~0
+        assert float((full_s[differ] + full_b[differ] + grad[differ]).abs().max()) <= 2e-4

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const unsigned* key, const
 //     continue from them (+= the chunk's own counts); 8 waves per block (8 instead of 16 dependent steps per wave and
 //     chunk, 24 instead of 16 waves per CU), every key ranked ONCE (the counting phase keeps the ranks), and the
 //     staging writes made independent of each other.
-// Same result as the chunk-at-a-time kernels bit for bit (integer arithmetic only, no atomic decides a slot).
+// Same result as the chunk-at-a-time kernels bit for bit: integer arithmetic only, and the one fetch-add whose RETURN value
+// is used (a digit's running count inside a wave) has a single lane per address and instruction, in program order.
 // ------------------------------------------------------------------------------------------
 #ifndef GCP_SORT_BIG
 #define GCP_SORT_BIG 4096  // (8192 with 16 waves and one block per CU: passes 0 / 1 no faster, measured)

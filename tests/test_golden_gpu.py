@@ -192,3 +192,30 @@ def test_gpu_error_vs_fp64_is_no_worse_than_the_sequential_fp32_path(device):
     e_gpu, e_cpu = rmsb(g.cpu()), rmsb(b32)
     assert e_gpu <= 1.25 * e_cpu + 1e-12, (e_gpu, e_cpu)
     print(f"rms error vs fp64: forward gpu {rms(y.cpu()):.3g} cpu-fp32 {rms(o32):.3g}; backward gpu {e_gpu:.3g} cpu-fp32 {e_cpu:.3g}")
+
+
+def test_wrappers_vs_reference_golden_cumsum_and_cutting_number(device):
+    """a5/a6 on the GPU — sort route (image size given / key range read back) and boxes route — vs what the reference's own
+    `_create_alpha_brend` / `grad_cumsum` returned on CPU for flag="cumsum" and for `cutting_number` (the carry rows of its
+    chunked calls, gs_model.py:557-559; tests/golden/wrappers_golden.npz): masks bit-exact, values within 1e-5."""
+    import cuda_kernel as ck
+
+    z = np.load(os.path.join(GOLD, "wrappers_golden.npz"))
+    for name in ("w_tiny", "w_small", "w_mid"):
+        rects = torch.from_numpy(z[name + "/rects"]).to(device)
+        anti = torch.from_numpy(z[name + "/anti_opacity"]).to(device)
+        grad = torch.from_numpy(z[name + "/grad"]).to(device)
+        w, h = (int(v) for v in z[name + "/width_height"])
+        for c in z[name + "/cuts"].tolist():
+            cut, tag = (None, "none") if c < 0 else (c, str(c))
+            if f"{name}/cumprod_{tag}/values" not in z.files:
+                continue
+            for kw in ({"image_size": (w, h)}, {}):
+                for flag in ("cumprod", "cumsum"):
+                    v, m = ck.create_alpha_brend(rects, anti, flag, cut, **kw)
+                    assert np.array_equal(m.cpu().numpy(), z[f"{name}/{flag}_{tag}/mask"]), (name, flag, tag)
+                    torch.testing.assert_close(v.cpu(), torch.from_numpy(z[f"{name}/{flag}_{tag}/values"]), atol=2e-5, rtol=TOL)
+                s, sm = ck.grad_cumsum(rects, grad, cut, **kw)
+                # deliberate deviation: our mask is in ORIGINAL order, the reference leaves it flipped
+                assert np.array_equal(sm.flip(0).cpu().numpy(), z[f"{name}/grad_cumsum_{tag}/mask_flipped"]), (name, tag)
+                torch.testing.assert_close(s.cpu(), torch.from_numpy(z[f"{name}/grad_cumsum_{tag}/values"]), atol=2e-5, rtol=TOL)

@@ -238,3 +238,35 @@ def test_multithreaded_oracle_is_bit_identical():
     g1 = co.cumprod_backward(x, y1, go, inv, inv_len)
     assert torch.equal(co.cumprod_backward_mt(x, y1, go, inv, inv_len, 4), g1)
     assert co.max_threads() >= 1
+
+
+def test_wrappers_oracle_equals_the_reference_with_cumsum_and_cutting_number():
+    """oracle/wrappers.py against the reference's own `_create_alpha_brend` / `grad_cumsum` run on CPU
+    (tests/golden/wrappers_golden.npz, generator make_wrappers_golden.py): flag="cumsum" and `cutting_number` with both
+    flags and through grad_cumsum — the branches function_golden.npz does not hold.  Masks bit-exact, values exact (the C
+    oracle reproduces the reference's host Thrust scans bit for bit)."""
+    import os
+
+    import numpy as np
+
+    from oracle import wrappers as ow
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "wrappers_golden.npz"))
+    n_checked = 0
+    for name in ("w_tiny", "w_small", "w_mid"):
+        rects = torch.from_numpy(z[name + "/rects"])
+        anti = torch.from_numpy(z[name + "/anti_opacity"])
+        grad = torch.from_numpy(z[name + "/grad"])
+        for c in z[name + "/cuts"].tolist():
+            cut, tag = (None, "none") if c < 0 else (c, str(c))
+            if f"{name}/cumprod_{tag}/values" not in z.files:
+                continue
+            for flag in ("cumprod", "cumsum"):
+                v, m, _, _ = ow.create_alpha_brend(rects, anti, flag, cut)
+                assert np.array_equal(m.numpy(), z[f"{name}/{flag}_{tag}/mask"]), (name, flag, tag)
+                assert np.array_equal(v.numpy(), z[f"{name}/{flag}_{tag}/values"]), (name, flag, tag)
+            s, sm = ow.grad_cumsum(rects, grad, cut)
+            assert np.array_equal(sm.numpy(), z[f"{name}/grad_cumsum_{tag}/mask_flipped"]), (name, tag)
+            assert np.array_equal(s.numpy(), z[f"{name}/grad_cumsum_{tag}/values"]), (name, tag)
+            n_checked += 1
+    assert n_checked >= 8

@@ -99,7 +99,9 @@ def test_wrappers_small_scenes_and_cutting_number(device, n_gauss, w, h, mh, see
 
 
 @pytest.mark.parametrize("n,wmax,hmax", [(1, 3, 3), (63, 7, 5), (4096, 1919, 1079), (4097, 50, 50), (100003, 1919, 1079),
-                                        (3_000_017, 3839, 2159), (50_000, 0, 0), (1_000_000, 9999, 200_000)])
+                                        (3_000_017, 3839, 2159), (50_000, 0, 0), (1_000_000, 9999, 200_000),
+                                        # 2, 3 and 5 chunks per block (the super-chunk length grows with n up to 8 at 6.7e7 keys)
+                                        (17_000_003, 1919, 1079), (26_000_017, 3839, 2159), (45_000_001, 1919, 1079)])
 def test_sort_rects_equals_torch_stable_sort_of_the_keys(device, n, wmax, hmax):
     """gcp_sort_rects: same sorted keys AND the same permutation as torch.sort(y*10000+x, stable=True), with the key
     width given and with the key range read back."""

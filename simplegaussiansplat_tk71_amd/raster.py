@@ -293,6 +293,9 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
     _require(x.dim() == 1, "values: expected a 1-D tensor")
     _require(off.numel() == bins.n_gauss + 1, "box_off: expected n_gauss + 1 offsets")
     out = torch.empty_like(x)
+    if x.numel() == 0 or bins.n_tile_pairs == 0:  # boxes that expand to nothing (all outside the image): nothing to scan
+        _require(x.numel() == 0, "values: the boxes expand to no pair at all")
+        return out
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().gcp_pairs_scan_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                                     bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),

@@ -265,3 +265,70 @@ def test_wrappers_full_size_cfg3_scene_properties(device):
     torch.testing.assert_close(full_s[both], full_b[both], atol=2e-4, rtol=1e-5)  # suffix sums of up to a few thousand N(0,1) terms
     if bool(differ.any()):  # where they differ, the kept value is the term itself up to round-off: the rest of the sum is ~0
         assert float((full_s[differ] + full_b[differ] + grad[differ]).abs().max()) <= 2e-4
+
+
+def _box_rects(start, end, w, h):
+    """The reference's rect list of clamped boxes, on the CPU (uitility.py:336-366)."""
+    rows = []
+    for (x0, y0), (x1, y1) in zip(start.tolist(), end.tolist()):
+        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, w), min(y1, h)
+        if x1 < x0 or y1 < y0:
+            continue
+        ys, xs = torch.meshgrid(torch.arange(y0, y1 + 1), torch.arange(x0, x1 + 1), indexing="ij")
+        rows.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], 1))
+    return torch.cat(rows).to(torch.int32) if rows else torch.zeros(0, 2, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("case", ["empty", "all_outside", "one_pixel_boxes", "clamped", "whole_image_stack", "deep_tile"])
+def test_boxes_route_edge_cases(device, case):
+    """create_alpha_brend_boxes / grad_cumsum_boxes on degenerate box sets, against the CPU statement on the rect list the
+    boxes expand to: no Gaussians; boxes entirely outside the image (they expand to nothing); 1x1 boxes; boxes reaching over
+    every image border (clamped, uitility.py:336-366); 150 boxes covering the whole image (every pixel 150 deep, tile lists
+    of several staging rounds); 700 boxes on one tile."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+
+    w, h = 45, 37
+    g = torch.Generator().manual_seed(7)
+    if case == "empty":
+        start = end = torch.zeros(0, 2, dtype=torch.int32)
+    elif case == "all_outside":
+        start = torch.tensor([[w + 3, 2], [-9, -9], [5, h + 1]], dtype=torch.int32)
+        end = torch.tensor([[w + 9, 8], [-2, -1], [9, h + 7]], dtype=torch.int32)
+    elif case == "one_pixel_boxes":
+        c = torch.stack([torch.randint(0, w + 1, (300,), generator=g), torch.randint(0, h + 1, (300,), generator=g)], 1).to(torch.int32)
+        start = end = c
+    elif case == "clamped":
+        start = torch.tensor([[-5, -5], [w - 3, -2], [-4, h - 2], [w - 1, h - 1], [-100, 10]], dtype=torch.int32)
+        end = torch.tensor([[3, 4], [w + 6, 5], [2, h + 9], [w + 50, h + 50], [w + 100, 12]], dtype=torch.int32)
+    elif case == "whole_image_stack":
+        start = torch.zeros(150, 2, dtype=torch.int32)
+        end = torch.tensor([[w, h]] * 150, dtype=torch.int32)
+    else:
+        lo = torch.stack([torch.randint(16, 24, (700,), generator=g), torch.randint(16, 24, (700,), generator=g)], 1)
+        start, end = lo.to(torch.int32), (lo + torch.randint(0, 8, (700, 2), generator=g)).to(torch.int32)
+    rects = _box_rects(start, end, w, h)
+    m = rects.size(0)
+    anti = 1.0 - 0.9 * torch.rand(m, generator=g)
+    if m:
+        anti[::11] = 0.0
+    grad = torch.randn(m, generator=g)
+    sd, ed = start.to(device), end.to(device)
+    for flag in ("cumprod", "cumsum"):
+        v, k = ck.create_alpha_brend_boxes(sd, ed, anti.to(device), w, h, flag)
+        assert k.numel() == m
+        if m == 0:
+            assert v.numel() == 0
+            continue
+        wv, wk, _, _ = ow.create_alpha_brend(rects, anti, flag)
+        assert torch.equal(k.cpu(), wk)
+        torch.testing.assert_close(v.cpu(), wv, atol=2e-4 if flag == "cumsum" else TOL, rtol=TOL)
+    v, k = ck.grad_cumsum_boxes(sd, ed, grad.to(device), w, h)
+    if m:
+        wv, wk_flipped = ow.grad_cumsum(rects, grad)
+        assert torch.equal(k.cpu(), wk_flipped.flip(0))
+        torch.testing.assert_close(v.cpu(), wv, atol=2e-4, rtol=TOL)
+    else:
+        assert v.numel() == 0 and k.numel() == 0
+    with pytest.raises(RuntimeError, match="pairs"):
+        ck.create_alpha_brend_boxes(sd, ed, torch.ones(m + 1, device=device), w, h, "cumprod")

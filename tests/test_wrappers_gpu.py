@@ -332,3 +332,13 @@ def test_boxes_route_edge_cases(device, case):
         assert v.numel() == 0 and k.numel() == 0
     with pytest.raises(RuntimeError, match="pairs"):
         ck.create_alpha_brend_boxes(sd, ed, torch.ones(m + 1, device=device), w, h, "cumprod")
+    # the same pair list through the sort route (an empty one included)
+    v, k = ck.create_alpha_brend(rects.to(device), anti.to(device), "cumprod", image_size=(w, h))
+    if m:
+        wv, wk, _, _ = ow.create_alpha_brend(rects, anti, "cumprod")
+        assert torch.equal(k.cpu(), wk)
+        torch.testing.assert_close(v.cpu(), wv, atol=TOL, rtol=TOL)
+    else:
+        assert v.numel() == 0 and k.numel() == 0 and k.dtype == torch.bool
+        s_, sk_ = ck.grad_cumsum(rects.to(device), grad.to(device))
+        assert s_.numel() == 0 and sk_.numel() == 0

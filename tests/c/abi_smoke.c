@@ -1,7 +1,8 @@
 /* abi_smoke.c — a plain C program on the C ABI (no Python, no torch, no C++): what a host written in
  * another language would do through its FFI.  Builds with gcc against include/grouped_cumprod_hip.h and
  * libgrouped_cumprod_hip.so; device memory comes from the HIP runtime's C API.
- * Runs the reference's known-answer test (reference: cuda_test.py:19-34) and a 1M-element scan.
+ * Runs the reference's known-answer test (reference: cuda_test.py:19-34), a 1M-element scan, and the three-stage
+ * _create_alpha_brend (gs_model.py:544-566) on the reference's worked example for it (uitility.py:383-393).
  * Exit code 0 = pass.  With argument "link-only" it only checks that the symbols resolve (no GPU). */
 #include <math.h>
 #include <stdio.h>
@@ -58,11 +59,47 @@ static int run_big(void) {
   return 0;
 }
 
+/* _create_alpha_brend through the C ABI alone: gcp_sort_rects -> gcp_cumprod_forward_indexed -> gcp_compact_finish.
+ * The reference's worked example of a grouped cumprod returned in ORIGINAL order (uitility.py:383-393):
+ * A = [1..7], groups (1,1),(1,2),(1,1),(1,2),(1,3),(1,1),(1,3) -> inclusive [1,2,3,8,5,18,35];
+ * _create_alpha_brend then divides by self -> exclusive [1,1,1,2,1,3,5], nothing dropped. */
+static int run_alpha_brend(void) {
+  const int64_t n = 7;
+  const int32_t rects[14] = {1, 1, 2, 1, 1, 1, 2, 1, 3, 1, 1, 1, 3, 1};  /* (x, y) with y = 1: key = 10000 + x */
+  const float a[7] = {1, 2, 3, 4, 5, 6, 7};
+  const float want_incl[7] = {1, 2, 3, 8, 5, 18, 35}, want_excl[7] = {1, 1, 1, 2, 1, 3, 5};
+  int32_t *d_r, *d_idx, *d_cnt; uint32_t* d_key; float *d_a, *d_incl, *d_val; uint8_t* d_keep; void *ws_sort, *ws_scan, *ws_cmp;
+  const size_t b_sort = gcp_sort_workspace_bytes(n), b_scan = gcp_workspace_bytes(n), b_cmp = gcp_compact_workspace_bytes(n);
+  if (hipMalloc((void**)&d_r, 56) || hipMalloc((void**)&d_idx, 28) || hipMalloc((void**)&d_key, 28) || hipMalloc((void**)&d_a, 28) ||
+      hipMalloc((void**)&d_incl, 28) || hipMalloc((void**)&d_val, 28) || hipMalloc((void**)&d_keep, 8) || hipMalloc((void**)&d_cnt, 4) ||
+      hipMalloc(&ws_sort, b_sort) || hipMalloc(&ws_scan, b_scan) || hipMalloc(&ws_cmp, b_cmp)) return 1;
+  hipMemcpy(d_r, rects, 56, 1); hipMemcpy(d_a, a, 28, 1);
+  CHECK(gcp_sort_rects(d_r, n, 14 /* bits of 10003 */, 0, d_key, d_idx, ws_sort, b_sort, NULL));
+  CHECK(gcp_workspace_init(ws_scan, b_scan, NULL));
+  CHECK(gcp_cumprod_forward_indexed(d_a, (const int32_t*)d_key, d_idx, d_incl, n, ws_scan, b_scan, NULL));
+  CHECK(gcp_compact_finish(d_incl, d_a, 0, n, 0, d_val, d_keep, d_cnt, ws_cmp, b_cmp, NULL));
+  hipDeviceSynchronize();
+  float incl[7], val[7]; uint8_t keep[7]; int32_t cnt = -1, idx[7]; uint32_t key[7];
+  hipMemcpy(incl, d_incl, 28, 2); hipMemcpy(val, d_val, 28, 2); hipMemcpy(keep, d_keep, 7, 2); hipMemcpy(&cnt, d_cnt, 4, 2);
+  hipMemcpy(idx, d_idx, 28, 2); hipMemcpy(key, d_key, 28, 2);
+  const int32_t want_idx[7] = {0, 2, 5, 1, 3, 4, 6};  /* stable: input order inside a key */
+  if (cnt != 7) { printf("alpha_brend: kept %d of 7\n", cnt); return 1; }
+  for (int i = 0; i < 7; ++i)
+    if (incl[i] != want_incl[i] || val[i] != want_excl[i] || keep[i] != 1 || idx[i] != want_idx[i] || key[i] != 10000u + (uint32_t)rects[2 * want_idx[i]]) {
+      printf("alpha_brend mismatch at %d: incl %g excl %g keep %d idx %d key %u\n", i, incl[i], val[i], keep[i], idx[i], key[i]);
+      return 1;
+    }
+  hipFree(d_r); hipFree(d_idx); hipFree(d_key); hipFree(d_a); hipFree(d_incl); hipFree(d_val); hipFree(d_keep); hipFree(d_cnt);
+  hipFree(ws_sort); hipFree(ws_scan); hipFree(ws_cmp);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (gcp_abi_version() != GCP_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
   if (argc > 1 && strcmp(argv[1], "link-only") == 0) { printf("link ok, tile = %d elements\n", gcp_tile_elems()); return 0; }
   if (run_kat()) return 1;
   if (run_big()) return 1;
+  if (run_alpha_brend()) return 1;
   printf("abi_smoke ok\n");
   return 0;
 }

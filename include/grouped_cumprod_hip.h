@@ -310,6 +310,31 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
                          float* inclusive, int32_t mode, void* stream);
 
+/* The rect list of the reference cut back into rectangles (gcp_pairs.hip), so that _create_alpha_brend / grad_cumsum can
+ * take the tile-walk route (gcp_pairs_scan_boxes) from nothing but `rects` — which `_create_rects` always writes as a
+ * concatenation of row-major boxes (gs_model.py:480-482, uitility.py:336-366).  Valid for ANY list: a list that is not made
+ * of boxes yields about as many rectangles as elements, and the caller then sorts instead.
+ *   gcp_rects_rows: rows = maximal runs (x, y), (x+1, y), ...  row_start[k] = index of the k-th row's first element,
+ *     row_start[rows] = n, row_xy[k] = its (x, y); both need room for gcp_rects_rows_capacity(n) entries.  info (device
+ *     int32[5]) = {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: some 4096-element stretch holds more than
+ *     1024 rows (or a coordinate does not fit x < 2^14, y < 2^17) — the outputs are then incomplete, sort instead.
+ *   gcp_rows_rectangles: rectangles = maximal runs of rows with equal first x and length and y growing by one.
+ *     rect_row[b] = first row of rectangle b (room for n_rows + 1 entries; rect_row[rectangles] = n_rows).  info (device
+ *     int32[2]) = {rectangles, 0}.
+ *   gcp_rectangle_boxes: start_xy / end_xy (inclusive, int32[n_rects][2]) and box_off (int32[n_rects + 1], box_off[b] =
+ *     index of the rectangle's first pair, box_off[n_rects] = n): the arguments of gcp_bin_tiles* and gcp_pairs_scan_boxes.
+ * Each cut is a stable stream compaction without atomics on the data path (per-tile counts, one exclusive scan, ranked
+ * writes); the first reads the M-sized list once.  ws: the matching *_workspace_bytes. */
+size_t gcp_rects_rows_workspace_bytes(int64_t n);
+int64_t gcp_rects_rows_capacity(int64_t n);
+int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
+                   void* ws, size_t ws_bytes, void* stream);
+size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows);
+int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream);
+int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const int32_t* row_xy, int64_t n_rects, int64_t n,
+                        int32_t* start_xy, int32_t* end_xy, int32_t* box_off, void* stream);
+
 size_t gcp_compact_workspace_bytes(int64_t n);
 int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
                        uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);

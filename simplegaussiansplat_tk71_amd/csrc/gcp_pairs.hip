@@ -1,0 +1,275 @@
+// gcp_pairs.hip — the rect list of the reference, taken apart again (rows a5 / a6).
+//
+// `_create_alpha_brend(rects, anti_opacity, flag)` (reference: gs_model.py:544-566) receives the splat-pixel pairs of one
+// camera as a flat list of pixel coordinates and sorts it by pixel — two radix sorts, a gather and a scan over M pairs.
+// But the list is never arbitrary: `_create_rects` (gs_model.py:480-482 -> Utilities.make_rect_points_parallel,
+// uitility.py:336-366) writes it as a concatenation of row-major boxes, one per Gaussian in depth order, and that
+// structure is enough to avoid the sort: cut the list back into rectangles, bin the rectangles into 16x16 tiles (K ~ 3
+// entries each) and let every pixel walk its tile's list (gcp_pairs_scan_boxes, gcp_raster.hip).  This file does the
+// cutting, for ANY list:
+//   a ROW      is a maximal run of consecutive elements (x, y), (x + 1, y), (x + 2, y), ...
+//   a RECTANGLE is a maximal run of consecutive rows with the same first x and the same length whose y grows by one.
+// By construction every rectangle is exactly the row-major expansion of [x0, x1] x [y0, y1], the rectangles in list order
+// reproduce the list, and no pixel occurs twice inside one — which is all the tile walk needs: the per-pixel order of the
+// pairs is the order of the rectangles.  Two Gaussians whose boxes happen to continue each other come out as one rectangle
+// (their pixels are disjoint: nothing changes); a list that is NOT made of boxes comes out as a great many tiny rectangles,
+// the caller sees their number and takes the general route (stable radix sort) instead.
+//
+// Both cuts are stable stream compactions without atomics on the data path: per-tile counts, one exclusive scan of the
+// counts, ranked writes.  The first cut reads the M-sized list ONCE: the counting pass parks each tile's few row records
+// (about 4096 / 13 of them) in a slot region of the tile's own, and the write pass moves them to their final places.
+// (A single-pass version with a decoupled look-back over the tile counts was built first and measured at 1.8 ms for
+// 1.65e8 pairs: 1500 tiles start together, every one of them has to add up the counts of all the others in front of it,
+// 64 per fabric round trip — the chain, not the data, set the pace.  This form takes 0.45 ms.)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gcp_device.hpp"
+#include "grouped_cumprod_hip.h"
+
+namespace {
+using namespace gcp;
+
+constexpr int kRowsPerThread = 4;                 // 16 elements per thread
+constexpr int kElemTile = 1024 * kRowsPerThread;  // 4096 elements per block
+constexpr int kSlotRows = 1024;                   // row records a tile may park: a list of boxes needs ~ 4096 / box width
+constexpr int kRowTile = 1024;                    // rows per block in the second cut, 4 per thread
+
+// Ranks of the set bits of m[0..ROWS) inside the block: thread t of wave w holds the flags of the 4 consecutive items
+// w * 256 * ROWS + r * 256 + lane * 4 + k.  rank[r] = flags in front of the thread's row r; returns the block's count.
+template <int ROWS>
+__device__ __forceinline__ int block_ranks(const unsigned (&m)[ROWS], int (&rank)[ROWS], int* s_w) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int wtot = 0;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int c = __builtin_popcount(m[r]);
+    const int inc = wave_incl_scan_i(c);
+    rank[r] = wtot + inc - c;
+    wtot += __builtin_amdgcn_readlane(inc, 63);
+  }
+  if (lane == 0) s_w[w] = wtot;
+  __syncthreads();
+  int woff = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < w) woff += s_w[j];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) rank[r] += woff;
+  return s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// ---- cut 1, pass 1: row starts of one tile -> the tile's slots; count; coordinate range ---------------------------------
+__global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict__ rects, i64 n, int2* __restrict__ slots /*[tiles][kSlotRows]: {index, x | y << 14}*/,
+                                                         int* __restrict__ cnt, int* __restrict__ info /*[5]: rows, max x, max y, min, overflow*/) {
+  __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 tile = blockIdx.x;
+  const i64 base = tile * kElemTile + (i64)w * (256 * kRowsPerThread);
+  int2 e[kRowsPerThread][4];
+  unsigned m[kRowsPerThread];
+  int mx = 0, my = 0, mn = 0x7fffffff;
+#pragma unroll
+  for (int r = 0; r < kRowsPerThread; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    int2 prev = make_int2(0x7ffffff0, 0x7ffffff0);  // nothing continues it
+    if (p > 0 && p <= n) prev = rects[p - 1];
+    m[r] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p + k < n) {
+        e[r][k] = rects[p + k];
+        const bool cont = e[r][k].x == prev.x + 1 && e[r][k].y == prev.y;
+        m[r] |= (cont ? 0u : 1u) << k;
+        prev = e[r][k];
+        mx = max(mx, e[r][k].x); my = max(my, e[r][k].y); mn = min(mn, min(e[r][k].x, e[r][k].y));
+      }
+    }
+  }
+  int rank[kRowsPerThread];
+  const int count = block_ranks<kRowsPerThread>(m, rank, s_w);
+  int2* const mine = slots + tile * kSlotRows;
+#pragma unroll
+  for (int r = 0; r < kRowsPerThread; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    int o = rank[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((m[r] >> k) & 1u) {
+        if (o < kSlotRows) mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+        ++o;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {  // coordinate range of the list (integer max / min: order-independent)
+    mx = max(mx, __shfl_xor(mx, o)); my = max(my, __shfl_xor(my, o)); mn = min(mn, __shfl_xor(mn, o));
+  }
+  if (lane == 0) { s_mx[w] = mx; s_my[w] = my; s_mn[w] = mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt[tile] = min(count, kSlotRows);
+    if (count > kSlotRows) info[4] = 1;  // rows shorter than 4 on average here: not a list of boxes
+    if (max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])) >= (1 << 14) || max(max(s_my[0], s_my[1]), max(s_my[2], s_my[3])) >= (1 << 17)) info[4] = 1;
+    atomicMax(info + 1, max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])));
+    atomicMax(info + 2, max(max(s_my[0], s_my[1]), max(s_my[2], s_my[3])));
+    atomicMin(info + 3, min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])));
+  }
+}
+
+// ---- cut 1, pass 2: the parked records to their final places -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
+                                                          i64 n_tiles, int* __restrict__ row_start, int2* __restrict__ row_xy,
+                                                          int* __restrict__ info) {
+  const i64 tile = blockIdx.x;
+  const int o0 = off[tile], c = off[tile + 1] - o0;
+  const int2* const mine = slots + tile * kSlotRows;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    const int2 q = mine[i];
+    row_start[o0 + i] = q.x;
+    row_xy[o0 + i] = make_int2(q.y & 0x3fff, (int)((unsigned)q.y >> 14));
+  }
+  if (tile == n_tiles - 1 && threadIdx.x == 0) {
+    info[0] = off[n_tiles];
+    row_start[off[n_tiles]] = (int)n;  // sentinel: the end of the last row
+  }
+}
+
+// ---- cut 2: rows -> rectangles (count, then write) -------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__ row_start, const int2* __restrict__ row_xy, i64 n_rows,
+                                                         int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ rect_row,
+                                                         int* __restrict__ info) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 tile = blockIdx.x;
+  const i64 p = tile * kRowTile + (i64)w * 256 + lane * 4;
+  unsigned m[1] = {0u};
+  // rows p-1 .. p+3: first x, y and length (row_start has n_rows + 1 entries)
+  int x0 = 0, y0 = 0, len0 = -1;
+  if (p > 0 && p <= n_rows) { const int2 q = row_xy[p - 1]; x0 = q.x; y0 = q.y; len0 = row_start[p] - row_start[p - 1]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (p + k < n_rows) {
+      const int2 q = row_xy[p + k];
+      const int len = row_start[p + k + 1] - row_start[p + k];
+      const bool cont = len0 >= 0 && q.x == x0 && len == len0 && q.y == y0 + 1;
+      m[0] |= (cont ? 0u : 1u) << k;
+      x0 = q.x; y0 = q.y; len0 = len;
+    }
+  }
+  int rank[1];
+  const int count = block_ranks<1>(m, rank, s_w);
+  if (!WRITE) {
+    if (threadIdx.x == 0) cnt[tile] = count;
+    return;
+  }
+  int o = off[tile] + rank[0];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if ((m[0] >> k) & 1u) rect_row[o++] = (int)(p + k);  // (as many rectangles as rows at most: the caller sized it so)
+  if (threadIdx.x == 0 && tile == (i64)gridDim.x - 1) {
+    info[0] = off[tile] + count;
+    rect_row[off[tile] + count] = (int)n_rows;  // sentinel
+  }
+}
+
+// rectangle b = rows [rect_row[b], rect_row[b + 1]): its box, and where its pairs start in the list
+__global__ void k_rectangle_boxes(const int* __restrict__ rect_row, const int* __restrict__ row_start, const int2* __restrict__ row_xy,
+                                  i64 n_rects, i64 n, int* __restrict__ start_xy, int* __restrict__ end_xy, int* __restrict__ box_off) {
+  const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_rects) return;
+  if (b == n_rects) { box_off[b] = (int)n; return; }
+  const int r0 = rect_row[b], r1 = rect_row[b + 1];
+  const int2 q = row_xy[r0];
+  const int len = row_start[r0 + 1] - row_start[r0];
+  start_xy[2 * b] = q.x;
+  start_xy[2 * b + 1] = q.y;
+  end_xy[2 * b] = q.x + len - 1;
+  end_xy[2 * b + 1] = q.y + (r1 - r0) - 1;
+  box_off[b] = row_start[r0];
+}
+
+inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gcp_rects_rows_workspace_bytes(int64_t n) {
+  const int64_t t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
+  return align256((size_t)t * kSlotRows * sizeof(int2)) + 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
+}
+
+int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
+                   void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || n > 0x7fffffffLL || row_capacity < 1 || !info) return GCP_ERR_INVALID_ARGUMENT;
+  GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), overflow
+  GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info + 3), 0x7fffffff, 1, stream));   // min coordinate
+  if (n == 0) return GCP_OK;
+  if (!rects_xy || !row_start || !row_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
+  if (ws_bytes < gcp_rects_rows_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  // every tile can deliver kSlotRows rows: the caller's arrays must hold them all (+ the sentinel), or nothing is written
+  if (row_capacity < n_tiles * (i64)kSlotRows + 1 && row_capacity < n + 1) return GCP_ERR_INVALID_ARGUMENT;
+  char* p = (char*)ws;
+  int2* slots = (int2*)p; p += align256((size_t)n_tiles * kSlotRows * sizeof(int2));
+  int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
+  int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
+  hipLaunchKernelGGL(k_rect_rows_local, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)rects_xy, (i64)n, slots, cnt, info);
+  GCP_HIP(hipGetLastError());
+  const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
+  if (st != GCP_OK) return st;
+  hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, (const int*)off, (i64)n, n_tiles,
+                     row_start, (int2*)row_xy, info);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int64_t gcp_rects_rows_capacity(int64_t n) {
+  const int64_t t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
+  const int64_t a = t * kSlotRows + 1, b = (n > 0 ? n : 0) + 1;
+  return a < b ? a : b;
+}
+
+size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows) {
+  const int64_t t = (n_rows > 0 ? n_rows + kRowTile - 1 : kRowTile) / kRowTile;
+  return 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
+}
+
+int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows < 0 || n_rows > 0x7fffffffLL || !info) return GCP_ERR_INVALID_ARGUMENT;
+  GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));  // rectangles, (unused)
+  if (n_rows == 0) return GCP_OK;
+  if (!row_start || !row_xy || !rect_row || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  const i64 n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+  if (ws_bytes < gcp_rows_rectangles_workspace_bytes(n_rows)) return GCP_ERR_WORKSPACE;
+  char* p = (char*)ws;
+  int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
+  int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
+  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, cnt,
+                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  GCP_HIP(hipGetLastError());
+  const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
+  if (st != GCP_OK) return st;
+  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows,
+                     (int*)nullptr, (const int*)off, rect_row, info);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const int32_t* row_xy, int64_t n_rects, int64_t n,
+                        int32_t* start_xy, int32_t* end_xy, int32_t* box_off, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rects < 0 || n < 0 || !box_off) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_rects > 0 && (!rect_row || !row_start || !row_xy || !start_xy || !end_xy)) return GCP_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)((n_rects + 1 + 255) / 256)), dim3(256), 0, stream, rect_row, row_start, (const int2*)row_xy,
+                     (i64)n_rects, (i64)n, start_xy, end_xy, box_off);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+}  // extern "C"

@@ -371,7 +371,10 @@ __device__ __forceinline__ void scan_tile(const ScanArgs& a, const i64 lt, float
 
   // key of the element just before this wave's chunk in scan order
   const i64 pn = REV ? (base + kTile - (i64)w * WT) : (base + (i64)w * WT - 1);
-  const bool nb_exists = REV ? (pn < n) : (pn >= 0);
+  // (both bounds in both directions: in a partial tile the waves whose chunk lies wholly past the end of the array must not
+  // touch key[pn] — up to 3 KB behind the allocation; rounds 1 and 2 read it, harmlessly wherever the allocator had mapped
+  // more memory behind the keys, and with a memory fault where it had not: found with rocgdb in round 3)
+  const bool nb_exists = (pn >= 0) && (pn < n);
   int nbk = 0;
   if (nb_exists) nbk = a.key[pn];
 

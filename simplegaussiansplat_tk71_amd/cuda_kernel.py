@@ -215,22 +215,60 @@ def pixel_key_bits(image_width, image_height):
     return max(1, (int(image_height) * 10000 + int(image_width)).bit_length())
 
 
-def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bits=None, image_size=None):
+def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bits=None, image_size=None, route="auto"):
     """Per-pixel exclusive transmittance (flag="cumprod") or exclusive prefix sum
     (flag="cumsum") of `anti_opacity`, returned in the ORIGINAL pair order.
 
-    reference: gs_model.py:544-566.  Same steps, same results, three stages instead of ten passes over M-length arrays:
-      1. key + stable sort (:546-547): the pixel key is computed inside the first radix pass straight from `rects`;
-      2. gather, grouped scan, un-sort (:548-555): ONE indexed scan — values gathered through the permutation on the
-         way in, inclusive results scattered through it on the way out;
-      3. drop `cutting_number` carry rows, compact the entries whose inclusive value is exactly 0 (:557-560, :575-578),
-         then inclusive / self (:562) or inclusive - self (:564): ONE stable stream compaction in original order.
-    Returns [values, mask].  Keyword-only extensions: `image_size=(width, height)` — what the Function holds as
-    image_width / image_height (gs_model.py:666); the sort then runs on compact pixel ids — or `key_bits`
-    (`pixel_key_bits(width, height)`); with neither the key range is read back once."""
+    reference: gs_model.py:544-566.  Same results, two routes:
+
+    route="boxes" — what `rects` always is when the reference calls this: `_create_rects` (gs_model.py:480-482,
+      uitility.py:336-366) writes one row-major box per Gaussian in depth order.  The list is cut back into rectangles
+      (raster.rects_to_boxes: two one-pass stream compactions), the rectangles are binned into 16x16 tiles, and every
+      pixel walks its tile's list front to back reading and writing each pair in place (raster.scan_boxes) — no M-sized
+      sort, every pixel scanned in the CPU path's own order.
+    route="sort" — any list of pixel coordinates: (1) key + stable sort (:546-547), the pixel key computed inside the first
+      radix pass straight from `rects`; (2) gather, grouped scan, un-sort (:548-555) as ONE indexed scan.
+    route="auto" (default) tries the cut and sorts when the list does not come apart into boxes (fewer than 8 pairs per
+      rectangle on average).
+    Either way the tail — drop `cutting_number` carry rows, compact the entries whose inclusive value is exactly 0
+    (:557-560, :575-578), inclusive / self (:562) or inclusive - self (:564) — is ONE stable stream compaction in
+    original order.  Returns [values, mask].  Keyword-only extensions for the sort route: `image_size=(width, height)` —
+    what the Function holds as image_width / image_height (gs_model.py:666); the sort then runs on compact pixel ids —
+    or `key_bits` (`pixel_key_bits(width, height)`); with neither the key range is read back once."""
+    if route not in ("auto", "boxes", "sort"):
+        raise ValueError(route)
     with torch.no_grad():
+        if route != "sort":
+            out = _rects_as_boxes(rects, anti_opacity, flag, cutting_number)
+            if out is not None:
+                return out
+            if route == "boxes":
+                raise RuntimeError("create_alpha_brend: rects do not come apart into boxes (route='boxes')")
         sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, anti_opacity, flag, cutting_number)
+
+
+_MAX_WALK_PIXELS = 1 << 26  # beyond this the tile grid of the walk is mostly empty tiles: sort instead
+
+
+def _rects_as_boxes(rects, values, flag, cutting_number=None):
+    """The boxes route from nothing but the rect list; None if the list is not a concatenation of boxes."""
+    if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
+        raise ValueError(flag)
+    rb = _raster.rects_to_boxes(rects)
+    if rb is None or (rb.width + 1) * (rb.height + 1) > _MAX_WALK_PIXELS:
+        return None
+    values = values.detach().contiguous()
+    n = values.numel()
+    if n != int(rects.shape[0]):
+        raise RuntimeError(f"values: {n} rows, rects has {int(rects.shape[0])}")
+    bins = _raster.bin_tiles(rb.start, rb.end, rb.width, rb.height)
+    mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
+    inclusive = _raster.scan_boxes(bins, rb.start, rb.end, rb.box_off, values, mode)
+    cut = int(cutting_number) if cutting_number else 0
+    begin, end = (0, n - cut) if flag == "cumsum_reverse" else (cut, n)
+    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, begin, end)
+    return [values_out, keep]
 
 
 def _scan_unsort_compact(sorted_key, index, anti_opacity, flag, cutting_number=None):
@@ -286,17 +324,26 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
         return _scan_boxes_compact(startpoint, endpoint, anti_opacity, image_width, image_height, flag)
 
 
-def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=None):
+def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=None, route="auto"):
     """Per-pixel exclusive SUFFIX sum of `grad` in original pair order.
 
     reference: gs_model.py:716-722 (flip, _create_alpha_brend(flag="cumsum"), flip).
     Flipping a stably sorted list and summing forward equals summing backward on the
-    un-flipped list, so this runs one reverse scan instead.  `cutting_number` counts
+    un-flipped list, so this walks the tile lists back to front (route "boxes") or runs one
+    indexed reverse scan (route "sort"); routes as for `create_alpha_brend`.  `cutting_number` counts
     rows at the START of the flipped arrays, i.e. the LAST rows of the inputs
     (gs_model.py:636 appends the carry rows at the end before the flip).  The mask is
     returned in ORIGINAL order (the reference leaves it flipped).
     """
+    if route not in ("auto", "boxes", "sort"):
+        raise ValueError(route)
     with torch.no_grad():
+        if route != "sort":
+            out = _rects_as_boxes(rects, grad, "cumsum_reverse", cutting_number)
+            if out is not None:
+                return out
+            if route == "boxes":
+                raise RuntimeError("grad_cumsum: rects do not come apart into boxes (route='boxes')")
         sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
 

@@ -303,6 +303,58 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
     return out
 
 
+@dataclass
+class RectBoxes:
+    """A rect list cut back into rectangles (`rects_to_boxes`): the boxes, in list order, that expand to it."""
+    start: torch.Tensor    # int32[R,2] (x, y) inclusive
+    end: torch.Tensor      # int32[R,2]
+    box_off: torch.Tensor  # int32[R+1]: first pair of every rectangle, [-1] = M
+    width: int             # largest x in the list
+    height: int            # largest y
+
+
+def rects_to_boxes(rects, min_mean_size=8):
+    """Cut the reference's rect list (int [M,2] (x, y), gs_model.py:480-482) back into the row-major rectangles it is a
+    concatenation of (csrc/gcp_pairs.hip).  Works on any list; returns None when the list does not look like boxes at all
+    (fewer than `min_mean_size` pairs per rectangle on average, or a stretch of 4096 pairs with more than 1024 rows: the
+    caller sorts instead).  Two device->host reads (row and rectangle counts)."""
+    r = _dev_tensor(rects, "rects", torch.int32, (2,))
+    m = r.size(0)
+    dev = r.device
+    if m == 0:
+        z = torch.zeros(0, 2, dtype=torch.int32, device=dev)
+        return RectBoxes(z, z.clone(), torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
+    lib = _lib.load()
+    cap = lib.gcp_rects_rows_capacity(m)
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        row_start = torch.empty(cap, dtype=torch.int32, device=dev)
+        row_xy = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+        info = torch.empty(5, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_rects_rows_workspace_bytes(m), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_rects_rows(r.data_ptr(), m, cap, row_start.data_ptr(), row_xy.data_ptr(), info.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), st), "gcp_rects_rows")
+        n_rows, max_x, max_y, mn, not_boxes = info.tolist()
+        del ws
+        _require(mn >= 0, "rects: negative coordinates are not supported")
+        if not_boxes:  # some stretch of the list has rows shorter than 4 on average: the general route
+            return None
+        rect_row = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+        info2 = torch.empty(2, dtype=torch.int32, device=dev)
+        ws2 = torch.empty(lib.gcp_rows_rectangles_workspace_bytes(n_rows), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_rows_rectangles(row_start.data_ptr(), row_xy.data_ptr(), n_rows, rect_row.data_ptr(), info2.data_ptr(),
+                                           ws2.data_ptr(), ws2.numel(), st), "gcp_rows_rectangles")
+        n_rects = int(info2[0].item())
+        if n_rects * min_mean_size > m:
+            return None
+        start = torch.empty(n_rects, 2, dtype=torch.int32, device=dev)
+        end = torch.empty(n_rects, 2, dtype=torch.int32, device=dev)
+        box_off = torch.empty(n_rects + 1, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcp_rectangle_boxes(rect_row.data_ptr(), row_start.data_ptr(), row_xy.data_ptr(), n_rects, m, start.data_ptr(),
+                                           end.data_ptr(), box_off.data_ptr(), st), "gcp_rectangle_boxes")
+    return RectBoxes(start, end, box_off, int(max_x), int(max_y))
+
+
 def stable_sort_keys(keys, key_bits=None):
     """Stable sort of non-negative int32 keys on the HIP library: returns (sorted_keys int32[n], index int32[n]) with
     sorted_keys == keys[index] and equal keys in input order — `torch.sort(keys, stable=True)` as the reference needs

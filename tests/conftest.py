@@ -8,10 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # A process that dies must say why.  glibc writes its fatal messages (heap corruption, ...) to the controlling terminal
-# unless told otherwise, and the HIP runtime reports a queue error (hardware exception in a kernel, a reset of the GPU by
-# another tenant of the host) only at log level >= 1: one full run of round 3 ended in a bare SIGABRT raised by a thread of
-# the runtime itself (no Python thread was current), with neither message (profiles/r03_unexplained_abort.log; not
-# reproduced by two further full runs and one run of that file alone).  Both must be set before the runtime starts.
+# unless told otherwise, and the HIP runtime is terse at log level 0: two runs of round 3 ended in a bare SIGABRT (an
+# out-of-bounds key read of partial scan tiles, since fixed: DESIGN.md §4).  Both must be set before the runtime starts.
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
 os.environ.setdefault("AMD_LOG_LEVEL", "1")
 

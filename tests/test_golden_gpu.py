@@ -91,14 +91,15 @@ def test_wrappers_vs_reference_function_golden(device):
     for name in ("wrap_small", "wrap_mid"):
         rects = torch.from_numpy(z[name + "/rects"]).to(device)
         anti = torch.from_numpy(z[name + "/anti_opacity"]).to(device)
-        T, mask = ck.create_alpha_brend(rects, anti, "cumprod")
-        assert np.array_equal(mask.cpu().numpy(), z[name + "/T_mask"])
-        torch.testing.assert_close(T.cpu(), torch.from_numpy(z[name + "/T"]), atol=TOL, rtol=TOL)
         grad = torch.from_numpy(z[name + "/grad"]).to(device)
-        S, smask = ck.grad_cumsum(rects, grad)
-        # deliberate deviation: our mask is in ORIGINAL order, the reference leaves it flipped
-        assert np.array_equal(smask.flip(0).cpu().numpy(), z[name + "/S_mask_flipped"])
-        torch.testing.assert_close(S.cpu(), torch.from_numpy(z[name + "/S"]), atol=TOL, rtol=TOL)
+        for route in ("sort", "boxes", "auto"):
+            T, mask = ck.create_alpha_brend(rects, anti, "cumprod", route=route)
+            assert np.array_equal(mask.cpu().numpy(), z[name + "/T_mask"]), route
+            torch.testing.assert_close(T.cpu(), torch.from_numpy(z[name + "/T"]), atol=TOL, rtol=TOL)
+            S, smask = ck.grad_cumsum(rects, grad, route=route)
+            # deliberate deviation: our mask is in ORIGINAL order, the reference leaves it flipped
+            assert np.array_equal(smask.flip(0).cpu().numpy(), z[name + "/S_mask_flipped"]), route
+            torch.testing.assert_close(S.cpu(), torch.from_numpy(z[name + "/S"]), atol=TOL, rtol=TOL)
 
 
 def test_autograd_functions(device):
@@ -210,7 +211,7 @@ def test_wrappers_vs_reference_golden_cumsum_and_cutting_number(device):
             cut, tag = (None, "none") if c < 0 else (c, str(c))
             if f"{name}/cumprod_{tag}/values" not in z.files:
                 continue
-            for kw in ({"image_size": (w, h)}, {}):
+            for kw in ({"image_size": (w, h), "route": "sort"}, {"route": "sort"}, {"route": "boxes"}, {}):
                 for flag in ("cumprod", "cumsum"):
                     v, m = ck.create_alpha_brend(rects, anti, flag, cut, **kw)
                     assert np.array_equal(m.cpu().numpy(), z[f"{name}/{flag}_{tag}/mask"]), (name, flag, tag)

@@ -599,3 +599,56 @@ def test_explicit_workspaces_and_the_cache_bound(device):
         torch.cuda.current_stream(device).wait_stream(st)
     assert torch.equal(outs[0], want)
     assert len(impl._workspaces) <= impl._MAX_CACHED
+
+
+@pytest.mark.parametrize("n", [1, 5, 176, 1000, 3000, 4100, 9000])
+def test_partial_tiles_read_nothing_past_the_end_of_their_arrays(device, n):
+    """Rounds 1 and 2 let the waves of a partial tile whose chunk lies wholly past the end of the array read the key in
+    front of their chunk — up to 3 KB behind the key array.  Harmless wherever the allocator has mapped more memory there,
+    a GPU memory fault where it has not (two aborted test runs in round 3, found with rocgdb).  Here every operand is the
+    LAST bytes of a 20 MiB allocation of its own (a separate hipMalloc of the caching allocator), so a read past the end
+    has nothing mapped to land in; results against the oracle as usual."""
+    gc, co = _mods()
+    seg = 20 * 1024 * 1024
+    keep = []
+
+    def at_end(t):
+        big = torch.empty(seg, dtype=torch.uint8, device=device)
+        nbytes = t.numel() * t.element_size()
+        v = big[seg - nbytes:].view(t.dtype)
+        v.copy_(t)
+        keep.append(big)
+        return v
+
+    key = make_keys(n, "poisson8", 3)
+    inv, inv_len = co.groups_from_key(key)
+    x, xs, go = make_values(n, 5), make_values(n, 6, "normal"), make_values(n, 7, "normal")
+    kd, xd, xsd, god, invd = at_end(key), at_end(x), at_end(xs), at_end(go), at_end(inv)
+    y = at_end(torch.zeros(n))
+    gc.grouped_cumprod_forward(xd, kd, y)
+    want = co.cumprod_forward(x, key)
+    assert_parity(y, want, co.cumprod_forward_f64(x, key), "cumprod at the end of an allocation")
+    yd = at_end(want)
+    g = at_end(torch.zeros(n))
+    gc.grouped_cumprod_backward(xd, yd, god, invd, g, inv_len.to(device))
+    assert_parity(g, co.cumprod_backward_f64(x, want, go, inv).float(), co.cumprod_backward_f64(x, want, go.abs(), inv), "backward")
+    gc.grouped_cumsum_forward(xsd, kd, y)
+    assert_parity(y, co.cumsum_forward(xs, key), co.cumsum_forward_f64(xs.abs(), key), "cumsum")
+    gc.grouped_cumsum_reverse(xsd, kd, y)
+    scale = co.cumsum_forward_f64(xs.abs().flip(0).contiguous(), key.flip(0).contiguous()).flip(0)
+    assert_parity(y, co.cumsum_reverse(xs, key), scale, "cumsum_reverse")
+    carry = at_end(torch.ones(inv_len.numel()))
+    gc.grouped_cumprod_forward_carry(xd, invd, carry, y)
+    assert_parity(y, want, co.cumprod_forward_f64(x, key), "carry variant")
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(n)).to(torch.int32)
+    pd = at_end(perm)
+    gc.grouped_cumprod_forward_indexed(xd, kd, pd, y)
+    ref = torch.empty(n, device=device)
+    tmp = torch.empty(n, device=device)
+    gc.grouped_cumprod_forward(xd[perm.long().to(device)].contiguous(), kd, tmp)
+    ref[perm.long().to(device)] = tmp
+    assert torch.equal(y, ref)
+    buf = at_end(x)
+    gc.grouped_cumprod_forward(buf, kd, buf)  # in place
+    assert_parity(buf, want, co.cumprod_forward_f64(x, key), "in place")
+    torch.cuda.synchronize()

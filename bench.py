@@ -202,6 +202,9 @@ WRAPPER_BYTES = {
 }
 WRAPPER_BOX_BYTES = {"tile-list walk": {"value read": 4, "inclusive value written": 4},
                      "compaction": {"count pass": 4, "write pass reads": 8, "mask": 1, "kept values": 4}}
+# the default route: the rect list cut back into rectangles (one read of the list; its row / rectangle records are ~1/13 of a
+# pair each, rounded up to 1 B/pair), then the boxes route
+WRAPPER_AUTO_BYTES = {"rect list -> rows -> rectangles": {"rects read once": 8, "row and rectangle records": 1}, **WRAPPER_BOX_BYTES}
 
 
 def wrapper_level(dev, workload):
@@ -238,10 +241,15 @@ def wrapper_level(dev, workload):
         ts.sort()
         return ts[len(ts) // 2]
 
-    t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h)))
-    t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h)))
-    t_a5_kb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits))
-    t_a5_rb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"))
+    # the reference's own call, nothing but (rects, values, flag): the list is cut back into boxes and walked
+    t_a5_auto = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"))
+    t_a6_auto = timed(lambda: ck.grad_cumsum(rects, grad))
+    t_cut = timed(lambda: raster.rects_to_boxes(rects))
+    # the general route (any list of coordinates): stable radix sort, indexed scan
+    t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort"))
+    t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort"))
+    t_a5_kb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits, route="sort"))
+    t_a5_rb = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", route="sort"))
     t_a5b = timed(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"))
     t_a6b = timed(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h))
     # stages of the rects route
@@ -261,6 +269,7 @@ def wrapper_level(dev, workload):
     t_walk = timed(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0))
     b_rects = sum(sum(v.values()) for v in WRAPPER_BYTES.values())
     b_boxes = sum(sum(v.values()) for v in WRAPPER_BOX_BYTES.values())
+    b_auto = sum(sum(v.values()) for v in WRAPPER_AUTO_BYTES.values())
 
     def roof(bytes_per_pair, ms):
         ach = bytes_per_pair * m / (ms * 1e-3) / 1e9
@@ -275,19 +284,31 @@ def wrapper_level(dev, workload):
         "kept_pairs": kept,
         "sort": f"compact pixel ids y*{w + 1}+x: {max(1, (h * (w + 1) + w).bit_length())} bits in 3 passes (image_size given); "
                 f"{bits}-bit keys y*10000+x with key_bits",
-        "create_alpha_brend_ms": t_a5,
-        "create_alpha_brend_key_bits_ms": t_a5_kb,
-        "grad_cumsum_ms": t_a6,
-        "create_alpha_brend_key_range_read_back_ms": t_a5_rb,
-        "create_alpha_brend_pairs_per_s": m / (t_a5 * 1e-3),
-        "grad_cumsum_pairs_per_s": m / (t_a6 * 1e-3),
-        "roofline": roof(b_rects, t_a5),
-        "stages_ms": {"sort_rects (3 radix passes)": t_sort, "indexed scan (cumprod)": t_scan, "indexed scan (suffix sum)": t_rev,
-                      "compact_finish": t_comp},
-        "stage_rooflines": {"sort": roof(sum(WRAPPER_BYTES["sort"].values()), t_sort),
-                            "indexed scan": roof(sum(WRAPPER_BYTES["indexed scan"].values()), t_scan),
-                            "compaction": roof(sum(WRAPPER_BYTES["compaction"].values()), t_comp)},
-        "byte_model": WRAPPER_BYTES,
+        # the call as the reference makes it: create_alpha_brend(rects, anti_opacity, flag) / grad_cumsum(rects, grad)
+        "create_alpha_brend_ms": t_a5_auto,
+        "grad_cumsum_ms": t_a6_auto,
+        "create_alpha_brend_pairs_per_s": m / (t_a5_auto * 1e-3),
+        "grad_cumsum_pairs_per_s": m / (t_a6_auto * 1e-3),
+        "route": "auto -> boxes: the rect list (a concatenation of row-major boxes, uitility.py:336-366) is cut back into rectangles, "
+                 "binned into tiles and walked; no M-sized sort",
+        "roofline": roof(b_auto, t_a5_auto),
+        "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin, "tile-list walk": t_walk, "compact_finish": t_comp},
+        "byte_model": WRAPPER_AUTO_BYTES,
+        "general_sort_route": {
+            "what": "route='sort': any list of pixel coordinates — key-in-sort stable radix sort, one indexed scan, the same compaction",
+            "create_alpha_brend_ms": t_a5,
+            "create_alpha_brend_key_bits_ms": t_a5_kb,
+            "grad_cumsum_ms": t_a6,
+            "create_alpha_brend_key_range_read_back_ms": t_a5_rb,
+            "pairs_per_s": m / (t_a5 * 1e-3),
+            "roofline": roof(b_rects, t_a5),
+            "stages_ms": {"sort_rects (3 radix passes)": t_sort, "indexed scan (cumprod)": t_scan, "indexed scan (suffix sum)": t_rev,
+                          "compact_finish": t_comp},
+            "stage_rooflines": {"sort": roof(sum(WRAPPER_BYTES["sort"].values()), t_sort),
+                                "indexed scan": roof(sum(WRAPPER_BYTES["indexed scan"].values()), t_scan),
+                                "compaction": roof(sum(WRAPPER_BYTES["compaction"].values()), t_comp)},
+            "byte_model": WRAPPER_BYTES,
+        },
         "from_boxes": {
             "what": "the same results from the boxes the rects were expanded from: tile binning + one walk of the tile lists + the same compaction",
             "create_alpha_brend_boxes_ms": t_a5b,

@@ -220,6 +220,10 @@ def function_kernels(src, tag, out):
 
 
 WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
+    ("k_rect_rows_local", "rect list -> rows: flags, per-tile row records, coordinate range (reads the rects once)", 8, "auto"),
+    ("k_rect_rows_gather", "rows: records to their final places", 0.6, "auto"),
+    ("k_rows_rectangles<false>", "rows -> rectangles: count", 0.3, "auto"),
+    ("k_rows_rectangles<true>", "rows -> rectangles: write", 0.3, "auto"),
     ("k_sort_hist2<true>", "sort pass 0: histogram (reads the rects)", 8, "rects"),
     ("k_sort_scatter2<true, true>", "sort pass 0: scatter (rects -> key + index)", 16, "rects"),
     ("k_sort_hist2<false>", "sort passes 1, 2: histogram (per pass)", 4, "rects"),
@@ -250,8 +254,9 @@ def wrappers(src, tag, out):
     fetch = {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "wr_fetch"), "FETCH_SIZE", pick).items()}
     write = {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "wr_write"), "WRITE_SIZE", pick).items()}
     lines = [f"# {tag}: rows a5 / a6 — create_alpha_brend / grad_cumsum (gs_model.py:544-566, :716-722) at the cfg3 scene, M = {m} pairs", "",
-             "`rocprofv3 --kernel-trace --stats` of `python3 tools/wrapper_bench.py cfg3 --profile` (create_alpha_brend(rects), "
-             "grad_cumsum(rects), create_alpha_brend_boxes, grad_cumsum_boxes, 4 times each) and separate `--pmc FETCH_SIZE` / `--pmc "
+             "`rocprofv3 --kernel-trace --stats` of `python3 tools/wrapper_bench.py cfg3 --profile` (create_alpha_brend(rects) and "
+             "grad_cumsum(rects) by the default route — the list cut into boxes and walked — and by the general sort route, "
+             "create_alpha_brend_boxes, grad_cumsum_boxes, 4 times each) and separate `--pmc FETCH_SIZE` / `--pmc "
              "WRITE_SIZE` passes of the same command.  HBM bytes = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950 "
              "correction of the guide; FETCH_SIZE halves only wide streaming reads, so for the gather / scatter kernels the figure "
              "is an upper bound).", "",

@@ -52,8 +52,10 @@ def main():
             w, h = sc["width"], sc["height"]
             bits = ck.pixel_key_bits(w, h)
             for _ in range(iters):
-                ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h))
-                ck.grad_cumsum(rects, grad, image_size=(w, h))
+                ck.create_alpha_brend(rects, anti, "cumprod")                                    # auto: cut into boxes, walk
+                ck.grad_cumsum(rects, grad)
+                ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort")  # the general route
+                ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort")
                 ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod")
                 ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h)
             torch.cuda.synchronize()
@@ -67,11 +69,14 @@ def main():
         out = {"workload": cfg, "pairs": m, "gaussians": int(sc["start"].size(0))}
         bits = ck.pixel_key_bits(w, h)
         out["key_bits"] = bits
-        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h)), iters)
-        out["create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", image_size=(w, h)), iters)
-        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h)), iters)
-        out["create_alpha_brend_key_bits_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits), iters)
-        out["create_alpha_brend_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)
+        out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)  # auto: cut into boxes, walk
+        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad), iters)
+        out["rects_to_boxes_ms"] = timeit(lambda: raster.rects_to_boxes(rects), iters)
+        out["sort_route_create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort"), iters)
+        out["sort_route_create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", image_size=(w, h), route="sort"), iters)
+        out["sort_route_grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort"), iters)
+        out["sort_route_key_bits_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits, route="sort"), iters)
+        out["sort_route_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", route="sort"), iters)
         out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
         out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
         if stages:

@@ -70,16 +70,31 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
   int2 e[kRowsPerThread][4];
   unsigned m[kRowsPerThread];
   int mx = 0, my = 0, mn = 0x7fffffff;
+  const bool vec = (((uintptr_t)rects) & 15u) == 0;
+#pragma unroll
+  for (int r = 0; r < kRowsPerThread; ++r) {  // all loads of the lane first: two 16-byte loads per row where the row is whole
+    const i64 p = base + r * 256 + lane * 4;
+    if (vec && p + 3 < n) {
+      const int4 a = *reinterpret_cast<const int4*>(rects + p);
+      const int4 b = *reinterpret_cast<const int4*>(rects + p + 2);
+      e[r][0] = make_int2(a.x, a.y); e[r][1] = make_int2(a.z, a.w); e[r][2] = make_int2(b.x, b.y); e[r][3] = make_int2(b.z, b.w);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[r][k] = (p + k < n) ? rects[p + k] : make_int2(0x7ffffff0, 0x7ffffff0);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < kRowsPerThread; ++r) {
     const i64 p = base + r * 256 + lane * 4;
-    int2 prev = make_int2(0x7ffffff0, 0x7ffffff0);  // nothing continues it
-    if (p > 0 && p <= n) prev = rects[p - 1];
+    // the element in front of the lane's four: the left neighbour's last one; lane 0 of a row fetches it
+    int2 prev;
+    prev.x = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].x);
+    prev.y = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].y);
+    if (lane == 0) prev = (p > 0 && p <= n) ? rects[p - 1] : make_int2(0x7ffffff0, 0x7ffffff0);  // (nothing continues the first element)
     m[r] = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (p + k < n) {
-        e[r][k] = rects[p + k];
         const bool cont = e[r][k].x == prev.x + 1 && e[r][k].y == prev.y;
         m[r] |= (cont ? 0u : 1u) << k;
         prev = e[r][k];

@@ -94,12 +94,47 @@ static int run_alpha_brend(void) {
   return 0;
 }
 
+/* The rect list cut back into rectangles through the C ABI (gcp_rects_rows -> gcp_rows_rectangles -> gcp_rectangle_boxes)
+ * on the same seven pairs: rows [(1,1),(2,1)], [(1,1),(2,1),(3,1)], [(1,1)], [(3,1)] — four one-row rectangles. */
+static int run_rect_cut(void) {
+  const int64_t n = 7;
+  const int32_t rects[14] = {1, 1, 2, 1, 1, 1, 2, 1, 3, 1, 1, 1, 3, 1};
+  const int64_t cap = gcp_rects_rows_capacity(n);
+  int32_t *d_r, *d_rs, *d_rxy, *d_info, *d_rr, *d_info2, *d_s, *d_e, *d_off; void *ws1, *ws2;
+  const size_t b1 = gcp_rects_rows_workspace_bytes(n);
+  if (hipMalloc((void**)&d_r, 56) || hipMalloc((void**)&d_rs, cap * 4) || hipMalloc((void**)&d_rxy, cap * 8) || hipMalloc((void**)&d_info, 20) ||
+      hipMalloc(&ws1, b1)) return 1;
+  hipMemcpy(d_r, rects, 56, 1);
+  CHECK(gcp_rects_rows(d_r, n, cap, d_rs, d_rxy, d_info, ws1, b1, NULL));
+  hipDeviceSynchronize();
+  int32_t info[5]; hipMemcpy(info, d_info, 20, 2);
+  if (info[0] != 4 || info[1] != 3 || info[2] != 1 || info[3] != 1 || info[4] != 0) { printf("rect cut: rows info %d %d %d %d %d\n", info[0], info[1], info[2], info[3], info[4]); return 1; }
+  const int64_t n_rows = info[0];
+  const size_t b2 = gcp_rows_rectangles_workspace_bytes(n_rows);
+  if (hipMalloc((void**)&d_rr, (n_rows + 1) * 4) || hipMalloc((void**)&d_info2, 8) || hipMalloc(&ws2, b2)) return 1;
+  CHECK(gcp_rows_rectangles(d_rs, d_rxy, n_rows, d_rr, d_info2, ws2, b2, NULL));
+  hipDeviceSynchronize();
+  int32_t n_rects = -1; hipMemcpy(&n_rects, d_info2, 4, 2);
+  if (n_rects != 4) { printf("rect cut: %d rectangles\n", n_rects); return 1; }
+  if (hipMalloc((void**)&d_s, n_rects * 8) || hipMalloc((void**)&d_e, n_rects * 8) || hipMalloc((void**)&d_off, (n_rects + 1) * 4)) return 1;
+  CHECK(gcp_rectangle_boxes(d_rr, d_rs, d_rxy, n_rects, n, d_s, d_e, d_off, NULL));
+  hipDeviceSynchronize();
+  int32_t st[8], en[8], off[5];
+  hipMemcpy(st, d_s, 32, 2); hipMemcpy(en, d_e, 32, 2); hipMemcpy(off, d_off, 20, 2);
+  const int32_t want_s[8] = {1, 1, 1, 1, 1, 1, 3, 1}, want_e[8] = {2, 1, 3, 1, 1, 1, 3, 1}, want_off[5] = {0, 2, 5, 6, 7};
+  if (memcmp(st, want_s, 32) || memcmp(en, want_e, 32) || memcmp(off, want_off, 20)) { printf("rect cut: boxes differ\n"); return 1; }
+  hipFree(d_r); hipFree(d_rs); hipFree(d_rxy); hipFree(d_info); hipFree(d_rr); hipFree(d_info2); hipFree(d_s); hipFree(d_e); hipFree(d_off);
+  hipFree(ws1); hipFree(ws2);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (gcp_abi_version() != GCP_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
   if (argc > 1 && strcmp(argv[1], "link-only") == 0) { printf("link ok, tile = %d elements\n", gcp_tile_elems()); return 0; }
   if (run_kat()) return 1;
   if (run_big()) return 1;
   if (run_alpha_brend()) return 1;
+  if (run_rect_cut()) return 1;
   printf("abi_smoke ok\n");
   return 0;
 }

@@ -245,6 +245,10 @@ def wrapper_level(dev, workload):
     t_a5_auto = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"))
     t_a6_auto = timed(lambda: ck.grad_cumsum(rects, grad))
     t_cut = timed(lambda: raster.rects_to_boxes(rects))
+    prep = ck.PreparedRects(rects)  # cut + binning once for the forward's and the backward's call on the same list
+    t_a5_prep = timed(lambda: ck.create_alpha_brend(prep, anti, "cumprod"))
+    t_a6_prep = timed(lambda: ck.grad_cumsum(prep, grad))
+    del prep
     # the general route (any list of coordinates): stable radix sort, indexed scan
     t_a5 = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort"))
     t_a6 = timed(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort"))
@@ -292,6 +296,8 @@ def wrapper_level(dev, workload):
         "route": "auto -> boxes: the rect list (a concatenation of row-major boxes, uitility.py:336-366) is cut back into rectangles, "
                  "binned into tiles and walked; no M-sized sort",
         "roofline": roof(b_auto, t_a5_auto),
+        "with_prepared_rects_ms": {"create_alpha_brend": t_a5_prep, "grad_cumsum": t_a6_prep,
+                                   "what": "cuda_kernel.PreparedRects(rects): cut + binning done once for the calls of one step"},
         "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin, "tile-list walk": t_walk, "compact_finish": t_comp},
         "byte_model": WRAPPER_AUTO_BYTES,
         "general_sort_route": {

@@ -42,6 +42,7 @@ __all__ = [
     "pixel_key_bits",
     "create_alpha_brend",
     "create_alpha_blend",
+    "PreparedRects",
     "grad_cumsum",
     "create_alpha_brend_boxes",
     "grad_cumsum_boxes",
@@ -244,25 +245,47 @@ def create_alpha_brend(rects, anti_opacity, flag, cutting_number=None, *, key_bi
                 return out
             if route == "boxes":
                 raise RuntimeError("create_alpha_brend: rects do not come apart into boxes (route='boxes')")
-        sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
+        sorted_inv, index = _raster.sort_rects(rects.rects if isinstance(rects, PreparedRects) else rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, anti_opacity, flag, cutting_number)
 
 
 _MAX_WALK_PIXELS = 1 << 26  # beyond this the tile grid of the walk is mostly empty tiles: sort instead
 
 
+class PreparedRects:
+    """A rect list cut into boxes and binned into tiles ONCE, for the several calls a step makes on the same list — the
+    reference's forward calls `_create_alpha_brend(rects, ...)` and its backward `grad_cumsum(rects, ...)` on the rects it
+    rebuilds from the same boxes (gs_model.py:601-612, :630-643).  Pass it wherever `rects` is expected:
+
+        prep = PreparedRects(rects)
+        T, mask = create_alpha_brend(prep, anti_opacity, "cumprod")
+        S, mask = grad_cumsum(prep, grad)
+
+    `boxes` is None when the list is not a concatenation of boxes; the calls then sort (`rects` is kept for that)."""
+
+    def __init__(self, rects):
+        self.rects = rects
+        self.shape = rects.shape
+        with torch.no_grad():
+            rb = _raster.rects_to_boxes(rects)
+            if rb is not None and (rb.width + 1) * (rb.height + 1) > _MAX_WALK_PIXELS:
+                rb = None
+            self.boxes = rb
+            self.bins = _raster.bin_tiles(rb.start, rb.end, rb.width, rb.height) if rb is not None else None
+
+
 def _rects_as_boxes(rects, values, flag, cutting_number=None):
     """The boxes route from nothing but the rect list; None if the list is not a concatenation of boxes."""
     if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
         raise ValueError(flag)
-    rb = _raster.rects_to_boxes(rects)
-    if rb is None or (rb.width + 1) * (rb.height + 1) > _MAX_WALK_PIXELS:
+    prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects)
+    rb, bins = prep.boxes, prep.bins
+    if rb is None:
         return None
     values = values.detach().contiguous()
     n = values.numel()
-    if n != int(rects.shape[0]):
-        raise RuntimeError(f"values: {n} rows, rects has {int(rects.shape[0])}")
-    bins = _raster.bin_tiles(rb.start, rb.end, rb.width, rb.height)
+    if n != int(prep.shape[0]):
+        raise RuntimeError(f"values: {n} rows, rects has {int(prep.shape[0])}")
     mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
     inclusive = _raster.scan_boxes(bins, rb.start, rb.end, rb.box_off, values, mode)
     cut = int(cutting_number) if cutting_number else 0
@@ -344,7 +367,7 @@ def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=N
                 return out
             if route == "boxes":
                 raise RuntimeError("grad_cumsum: rects do not come apart into boxes (route='boxes')")
-        sorted_inv, index = _raster.sort_rects(rects, key_bits, image_size)
+        sorted_inv, index = _raster.sort_rects(rects.rects if isinstance(rects, PreparedRects) else rects, key_bits, image_size)
         return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
 
 

@@ -435,3 +435,29 @@ def test_rects_to_boxes_on_lists_that_are_not_boxes(device):
     if b_v is not None:
         assert torch.equal(b_m, s_m)
         torch.testing.assert_close(b_v, s_v, atol=TOL, rtol=TOL)
+
+
+def test_prepared_rects_serve_several_calls(device):
+    """`PreparedRects`: the cut and the binning done once for the forward's create_alpha_brend and the backward's
+    grad_cumsum on the same list (gs_model.py:601-612, :630-643) — same results as the plain calls, bit for bit; a list
+    that is not made of boxes is carried along and sorted."""
+    import cuda_kernel as ck
+
+    sc = make_scene(400, 100, 70, 9, 3)
+    rects, _ = _rects_of(sc, device)
+    g = torch.Generator().manual_seed(1)
+    anti = (1.0 - 0.9 * torch.rand(rects.size(0), generator=g)).to(device)
+    grad = torch.randn(rects.size(0), generator=g).to(device)
+    prep = ck.PreparedRects(rects)
+    assert prep.boxes is not None
+    for flag in ("cumprod", "cumsum"):
+        a, b = ck.create_alpha_brend(prep, anti, flag), ck.create_alpha_brend(rects, anti, flag)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a, b = ck.grad_cumsum(prep, grad, 7), ck.grad_cumsum(rects, grad, 7)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    rnd = torch.stack([torch.randint(0, 50, (5000,), generator=g), torch.randint(0, 40, (5000,), generator=g)], 1).to(torch.int32).to(device)
+    prep = ck.PreparedRects(rnd)
+    assert prep.boxes is None
+    v = (1.0 - 0.9 * torch.rand(5000, generator=g)).to(device)
+    a, b = ck.create_alpha_brend(prep, v, "cumprod"), ck.create_alpha_brend(rnd, v, "cumprod", route="sort")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -461,3 +461,52 @@ def test_prepared_rects_serve_several_calls(device):
     v = (1.0 - 0.9 * torch.rand(5000, generator=g)).to(device)
     a, b = ck.create_alpha_brend(prep, v, "cumprod"), ck.create_alpha_brend(rnd, v, "cumprod", route="sort")
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_wrapper_and_function_kernels_read_nothing_past_the_end_of_their_inputs(device):
+    """Every input of the sort / cut / walk / compaction kernels and of the fused Function placed at the very END of a 20 MiB
+    allocation of its own (cf. test_scan_gpu.py::test_partial_tiles_read_nothing_past_the_end_of_their_arrays): a read past
+    an array's end has nothing mapped to land in.  Results against the plain calls."""
+    import cuda_kernel as ck
+
+    seg = 20 * 1024 * 1024
+    keep = []
+
+    def at_end(t):
+        t = t.contiguous()
+        big = torch.empty(seg, dtype=torch.uint8, device=device)
+        nbytes = t.numel() * t.element_size()
+        v = big[seg - nbytes:].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        keep.append(big)
+        return v
+
+    sc = make_scene(333, 97, 71, 9, 13)
+    rects, _ = _rects_of(sc, device)
+    m = rects.size(0)
+    g = torch.Generator().manual_seed(2)
+    anti = (1.0 - 0.9 * torch.rand(m, generator=g)).to(device)
+    anti[::17] = 0.0
+    grad = torch.randn(m, generator=g).to(device)
+    r_e, a_e, g_e = at_end(rects), at_end(anti), at_end(grad)
+    s_e, e_e = at_end(sc["start"].to(device)), at_end(sc["end"].to(device))
+    for route in ("sort", "boxes"):
+        want, got = ck.create_alpha_brend(rects, anti, "cumprod", route=route), ck.create_alpha_brend(r_e, a_e, "cumprod", route=route)
+        assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+        want, got = ck.grad_cumsum(rects, grad, 3, route=route), ck.grad_cumsum(r_e, g_e, 3, route=route)
+        assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    want, got = ck.create_alpha_brend_boxes(sc["start"].to(device), sc["end"].to(device), anti, 97, 71), ck.create_alpha_brend_boxes(s_e, e_e, a_e, 97, 71)
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    # the fused Function: binning, blend forward, blend backward
+    outs = []
+    for place in (lambda t: t.to(device), lambda t: at_end(t.to(device))):
+        vinv = place(sc["vinv"]).requires_grad_(True)
+        op = place(sc["opacity"]).requires_grad_(True)
+        l_d = place(sc["l_d"]).requires_grad_(True)
+        img = ck.custom_autograd_grouped_cumprod.apply(place(sc["boxsize"]), None, place(sc["start"]), place(sc["end"]), place(sc["mean"]),
+                                                       vinv, op, l_d, 97, 71)
+        (img * place(sc["wimg"])).sum().backward()
+        outs.append((img.detach(), vinv.grad, op.grad, l_d.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()

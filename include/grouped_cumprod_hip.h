@@ -305,10 +305,11 @@ int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, vo
  *   inclusive[pair] = product (mode 0) / sum (mode 1) of x over the pairs of the same pixel up to and including this one
  *   in depth order; mode 2: sum from this one to the deepest (grad_cumsum's flipped scan, gs_model.py:716-722).
  * Every pixel is scanned sequentially in depth order (the association of the CPU statement).  8 B / pair.  Feed the result
- * to gcp_compact_finish. */
+ * to gcp_compact_finish.  n_pairs = M = box_off[n_gauss], the length of x and inclusive (< 2^31; up to 2^30 the kernel
+ * addresses pairs by 32-bit byte offsets). */
 int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                         float* inclusive, int32_t mode, void* stream);
+                         float* inclusive, int64_t n_pairs, int32_t mode, void* stream);
 
 /* The rect list of the reference cut back into rectangles (gcp_pairs.hip), so that _create_alpha_brend / grad_cumsum can
  * take the tile-walk route (gcp_pairs_scan_boxes) from nothing but `rects` — which `_create_rects` always writes as a

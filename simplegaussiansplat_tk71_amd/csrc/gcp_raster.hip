@@ -984,13 +984,85 @@ __global__ __launch_bounds__(256) void k_pixel_lists(const BlendArgs a, int* __r
 // index array: 8 B per pair.  Lanes of one pixel row read and write consecutive addresses (64 B per box row and tile).
 // ------------------------------------------------------------------------------------------
 constexpr int kWalkStage = 64;  // list entries staged per round: one hit word per wave
-template <int MODE>  // 0 cumprod, 1 cumsum, 2 reverse cumsum
+#ifndef GCP_WALK_BATCH
+#define GCP_WALK_BATCH 8
+#endif
+#ifndef GCP_WALK_DBG
+#define GCP_WALK_DBG 0
+#endif
+constexpr int kWalkBatch = GCP_WALK_BATCH;  // listed entries whose loads are in flight together (a power of two)
+
+// A batch: kWalkBatch listed entries of one wave's hit word.  The staged records are read together and the values
+// loaded together (walk_load); walk_fold then multiplies / adds them in list order and stores the running values.
+// Straight-line code — no branch around a load: a lane outside the box, or a slot past the last hit (record -1: no bits
+// set), reads pair 0 and discards it.  gfx950 counts loads and stores in ONE in-order counter, and behind a conditional
+// load the compiler can only wait for "everything": every store of a batch then waited for the store before it.
+// WIDE = false: pair positions are 32-bit byte offsets from the (wave-uniform) array bases — no 64-bit address
+// arithmetic per pair.
+struct WalkBatch {
+  bool in[kWalkBatch];
+  unsigned off[kWalkBatch];
+  float v[kWalkBatch];
+};
+template <int MODE, bool WIDE>
+__device__ __forceinline__ void walk_load(WalkBatch& b, unsigned long long& hits, const int4* __restrict__ ent,
+                                          unsigned lane_bits, int ly, int lxo, const float* __restrict__ x) {
+  int k[kWalkBatch];
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {  // scalar: the next set bit, -1 when none is left
+    if (MODE == 2) {
+      k[u] = hits ? 63 - __builtin_clzll(hits) : -1;
+      hits &= ~(1ull << (k[u] & 63));
+    } else {
+      k[u] = hits ? __builtin_ctzll(hits) : -1;
+      hits &= hits - 1ull;
+    }
+  }
+  int4 e[kWalkBatch];
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) e[u] = ent[k[u]];
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {
+    asm volatile("" :: "v"(e[u].x), "v"(e[u].y));  // the whole record is read ahead of the membership test
+    b.in[u] = ((unsigned)e[u].z & lane_bits) == lane_bits;
+    const unsigned o = (unsigned)e[u].x + (unsigned)lxo + __umul24((unsigned)ly, (unsigned)e[u].y);
+    b.off[u] = b.in[u] ? o : 0u;
+#if (GCP_WALK_DBG & 1)
+    b.v[u] = __int_as_float(0x3f7fff00 + b.off[u] % 7);
+#else
+    b.v[u] = WIDE ? x[b.off[u]] : *(const float*)((const char*)x + b.off[u]);
+#endif
+  }
+}
+template <int MODE, bool WIDE>
+__device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict__ out, float& acc) {
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {
+    if (b.in[u]) {
+      acc = (MODE == 0) ? acc * b.v[u] : acc + b.v[u];
+#if (GCP_WALK_DBG & 2)
+      if (acc == 12345.678f)
+#endif
+      {
+        if (WIDE) out[b.off[u]] = acc;
+        else *(float*)((char*)out + b.off[u]) = acc;
+      }
+    }
+  }
+}
+
+template <int MODE, bool WIDE>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
                                                           const float* __restrict__ x, float* __restrict__ out, int n_tiles,
                                                           int xcd_remap) {
-  __shared__ int4 s_box[kWalkStage];   // x0, y0, x1, y1 (clamped to the image)
-  __shared__ int s_off[kWalkStage];    // first Gaussian-major pair of the entry's Gaussian
+  // a staged entry: x = position of the tile's first pixel in the entry's box run (box_off + (tile_y0 - y0) * width +
+  // (tile_x0 - x0), may lie before the run), y = box width — both in bytes unless WIDE —, z = the box as bits over the
+  // tile's columns (0-15) and rows (16-31).  A lane's pair is x + row * y + column, and it is in the box when both of
+  // its bits are set: membership is one AND and one compare.
+  __shared__ int4 s_ent_[kWalkStage + 1];
   __shared__ unsigned long long s_hits[4];
+  int4* const s_ent = s_ent_ + 1;  // record -1: no bits set, what a batch reads for the slots past its last hit
+  if (threadIdx.x == 0) s_ent[-1] = make_int4(0, 0, 0, 0);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // A box is one contiguous run of the pair arrays (row-major, uitility.py:336-366) but lies across up to 2 x 2 tiles: with
@@ -1000,8 +1072,9 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
   const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);
   if (tile < 0) return;
   const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
-  const int px = tile_x0 + (lane & 15);
-  const int py = tile_y0 + w * 4 + (lane >> 4);
+  constexpr int kUnit = WIDE ? 1 : 4;
+  const int lxo = (lane & 15) * kUnit, ly = w * 4 + (lane >> 4);
+  const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + ly));
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   const int nrounds = (last - first + kWalkStage - 1) / kWalkStage;
   float acc = (MODE == 0) ? 1.0f : 0.0f;
@@ -1010,54 +1083,41 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
     const int base = first + q * kWalkStage;
     const int cnt = min(kWalkStage, last - base);
     __syncthreads();
-    if (threadIdx.x < kWalkStage) {  // wave 0 stages the round
-      const int j = threadIdx.x;
+    if (w == 0) {  // wave 0 stages the round (a fifth wave staging one round ahead of the walkers: measured 6 % slower)
       unsigned rm = 0u;
-      if (j < cnt) {
-        const i64 g = a.tile_list[base + j];
+      if (lane < cnt) {
+        const i64 g = a.tile_list[base + lane];
         Box b;
         load_box(a.start, a.end, g, a.W, a.H, b);
-        s_box[j] = make_int4(b.x0, b.y0, b.x1, b.y1);
-        s_off[j] = box_off[g];
+        const int wd = b.x1 - b.x0 + 1;
+        const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
         const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
-        rm = (r1 >= r0) ? ((2u << r1) - (1u << r0)) : 0u;
+        const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
+        rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
+        // modulo 2^32: every pair of the list lies below 2^32 bytes (2^31 pairs when WIDE), whatever the tile's corner does
+        const unsigned p0 = (unsigned)box_off[g] + (unsigned)((tile_y0 - b.y0) * wd + (tile_x0 - b.x0));
+        s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(cm | (rm << 16)), 0);
       }
 #pragma unroll
       for (int w2 = 0; w2 < 4; ++w2) {
         const unsigned long long touched = __ballot(((rm >> (4 * w2)) & 0xfu) != 0u);
-        if (j == 0) s_hits[w2] = touched;
+        if (lane == 0) s_hits[w2] = touched;
       }
     }
     __syncthreads();
     unsigned long long hits = uniform64(s_hits[w]);
-    // four listed entries at a time: their loads are issued together, then folded in list order
-    while (hits) {
-      int kk[4];
-      int idx[4];
-      bool in[4];
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        kk[u] = -1;
-        if (hits) {
-          kk[u] = (MODE == 2) ? (63 - __builtin_clzll(hits)) : __builtin_ctzll(hits);
-          hits &= ~(1ull << kk[u]);
-        }
-        in[u] = false;
-        idx[u] = 0;
-        if (kk[u] >= 0) {  // wave-uniform
-          const int4 bx = s_box[kk[u]];
-          in[u] = (px >= bx.x) & (px <= bx.z) & (py >= bx.y) & (py <= bx.w);
-          idx[u] = s_off[kk[u]] + (py - bx.y) * (bx.z - bx.x + 1) + (px - bx.x);
-        }
-        v[u] = in[u] ? x[idx[u]] : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (in[u]) {
-          acc = (MODE == 0) ? acc * v[u] : acc + v[u];
-          out[idx[u]] = acc;
-        }
+    // two batches in flight: the loads of the next one are issued before the stores of the one in hand, so that waiting
+    // for loaded values (in-order counter) never waits for the stores just issued
+    if (hits) {
+      WalkBatch A, B;
+      walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
+      for (;;) {
+        if (!hits) { walk_fold<MODE, WIDE>(A, out, acc); break; }
+        walk_load<MODE, WIDE>(B, hits, s_ent, lane_bits, ly, lxo, x);
+        walk_fold<MODE, WIDE>(A, out, acc);
+        if (!hits) { walk_fold<MODE, WIDE>(B, out, acc); break; }
+        walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
+        walk_fold<MODE, WIDE>(B, out, acc);
       }
     }
   }
@@ -1614,20 +1674,25 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
 
 int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                         float* inclusive, int32_t mode, void* stream_) {
+                         float* inclusive, int64_t n_pairs, int32_t mode, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
-  if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2) return GCP_ERR_INVALID_ARGUMENT;
-  if (n_gauss == 0) return GCP_OK;
+  if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2 || n_pairs < 0 || n_pairs > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_gauss == 0 || n_pairs == 0) return GCP_OK;
   if (!start_xy || !end_xy || !tile_list || !box_off || !x || !inclusive || x == inclusive) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
   static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 1; }();
+  // pair positions as 32-bit byte offsets while the list is no longer than 2^30 pairs (GCP_WALK_WIDE=1 forces the other form)
+  const char* fw = getenv("GCP_WALK_WIDE");  // read per call: the tests switch it inside one process
+  const bool wide = (fw && *fw && atoi(fw) != 0) || n_pairs > (1LL << 30);
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);
-  if (mode == 0) hipLaunchKernelGGL((k_pairs_scan_boxes<0>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
-  else if (mode == 1) hipLaunchKernelGGL((k_pairs_scan_boxes<1>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
-  else hipLaunchKernelGGL((k_pairs_scan_boxes<2>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap);
+#define GCP_WALK(M, W_) hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap)
+  if (mode == 0) { if (wide) GCP_WALK(0, true); else GCP_WALK(0, false); }
+  else if (mode == 1) { if (wide) GCP_WALK(1, true); else GCP_WALK(1, false); }
+  else { if (wide) GCP_WALK(2, true); else GCP_WALK(2, false); }
+#undef GCP_WALK
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

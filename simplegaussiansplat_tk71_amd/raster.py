@@ -299,7 +299,7 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().gcp_pairs_scan_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                                     bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
-                                                    out.data_ptr(), int(mode), _stream(x.device)), "gcp_pairs_scan_boxes")
+                                                    out.data_ptr(), x.numel(), int(mode), _stream(x.device)), "gcp_pairs_scan_boxes")
     return out
 
 

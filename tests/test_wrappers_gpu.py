@@ -287,6 +287,49 @@ def _box_rects(start, end, w, h):
     return torch.cat(rows).to(torch.int32) if rows else torch.zeros(0, 2, dtype=torch.int32)
 
 
+def test_walk_addresses_pairs_either_way(device, monkeypatch):
+    """The tile-list walk addresses pairs by 32-bit byte offsets up to 2^30 pairs and by element index beyond
+    (gcp_pairs_scan_boxes); GCP_WALK_WIDE=1 forces the second form: same bits on a scene and on the clamped / deep cases."""
+    from simplegaussiansplat_tk71_amd import raster, synthetic
+
+    sc, rects, anti, grad = synthetic.make_scene_pairs("cfg2", seed=3, device=device)
+    g = torch.Generator().manual_seed(5)
+    lo = torch.stack([torch.randint(-6, 40, (900,), generator=g), torch.randint(-6, 30, (900,), generator=g)], 1)
+    small = (lo.to(torch.int32).to(device), (lo + torch.randint(0, 20, (900, 2), generator=g)).to(torch.int32).to(device), 45, 37)
+    for start, end, w, h in ((sc["start"], sc["end"], sc["width"], sc["height"]), small):
+        bins = raster.bin_tiles(start, end, w, h)
+        boff = raster.box_offsets(start, end, w, h)
+        m = int(boff[-1])
+        vals = 1.0 - 0.9 * torch.rand(m, device=device)
+        for mode in (0, 1, 2):
+            monkeypatch.delenv("GCP_WALK_WIDE", raising=False)
+            narrow = raster.scan_boxes(bins, start, end, boff, vals, mode)
+            monkeypatch.setenv("GCP_WALK_WIDE", "1")
+            wide = raster.scan_boxes(bins, start, end, boff, vals, mode)
+            assert torch.equal(narrow, wide), mode
+
+
+def test_walk_beyond_2_30_pairs(device):
+    """1100 boxes of 1000 x 1000 pixels = 1.1e9 pairs (> 2^30: byte offsets no longer fit 32 bits, the walk addresses by
+    element): every pixel is 1100 deep, a sum of ones counts the layers — front to back and, mode 2, back to front."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    n, side = 1100, 1000
+    start = torch.zeros(n, 2, dtype=torch.int32, device=device)
+    end = torch.full((n, 2), side - 1, dtype=torch.int32, device=device)
+    bins = raster.bin_tiles(start, end, side - 1, side - 1)
+    boff = raster.box_offsets(start, end, side - 1, side - 1)
+    m = int(boff[-1])
+    assert m == n * side * side and m > (1 << 30)
+    ones = torch.ones(m, device=device)
+    layer = torch.arange(1, n + 1, device=device, dtype=torch.float32).view(n, 1)
+    out = raster.scan_boxes(bins, start, end, boff, ones, 1)
+    assert bool((out.view(n, -1) == layer).all())
+    del out
+    out = raster.scan_boxes(bins, start, end, boff, ones, 2)
+    assert bool((out.view(n, -1) == (n + 1 - layer)).all())
+
+
 @pytest.mark.parametrize("case", ["empty", "all_outside", "one_pixel_boxes", "clamped", "whole_image_stack", "deep_tile"])
 def test_boxes_route_edge_cases(device, case):
     """create_alpha_brend_boxes / grad_cumsum_boxes on degenerate box sets, against the CPU statement on the rect list the

@@ -264,11 +264,6 @@ int gcp_blend_backward(const int32_t* start_xy, const int32_t* end_xy, const flo
                        float* grad_vinv, float* grad_opacity, float* grad_l, void* ws,
                        size_t ws_bytes, void* stream);
 
-/* f2, CSR export for callers of the scan API: per-pixel pair counts (row-major over the
- * (H+1)x(W+1) image = ascending pixel key y*10000+x) and box sizes; then, given their exclusive
- * prefix sums, pair_gauss[M] (Gaussian of every pair, pixel-major, depth order) and
- * pair_index[M] (the pair's position in the reference's Gaussian-major rect list) — i.e. the
- * `index` torch.sort(stable) returns at gs_model.py:547, bit for bit. */
 /* Stable sort of n uint32 keys that also returns the permutation: keys_out[i] = keys_in[index_out[i]], equal
  * keys keep their input order — what the reference asks of torch.sort for its pixel keys (gs_model.py:546-547;
  * depth order inside a pixel rides on that stability).  LSD radix sort over the low `key_bits` bits (8 per
@@ -290,14 +285,6 @@ int gcp_sort_rects(const int32_t* rects_xy, int64_t n, int32_t key_bits, int32_t
  * what a caller needs to choose key_bits when it does not know the image size. */
 int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, void* stream);
 
-/* The tail of _create_alpha_brend (gs_model.py:557-564) on the un-sorted inclusive scan values, elements [begin, end)
- * of the original pair order (the reference's `cutting_number` slices, :557-559):
- *   keep[j]   = inclusive[begin + j] != 0                                   (:560, :575-578)
- *   values[k] = inclusive[i] / self[i] (mode 0, :562) or inclusive[i] - self[i] (mode 1, :564)
- *               for the k-th kept i, in order                               (the boolean-mask compaction)
- * count_dev[0] (device int32) receives the number of kept elements.  Stable stream compaction in two launches (per-tile
- * counts, then ranks from one exclusive scan of them): no atomics, deterministic.  values needs room for end - begin
- * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 17 B / element. */
 /* Rows a5 / a6 for callers that still hold the boxes their rect list was expanded from (gs_model.py:601 -> :607): key,
  * stable sort, gather, grouped scan and un-sort of _create_alpha_brend (gs_model.py:546-555) as ONE walk of the tile lists of
  * gcp_bin_tiles*.  x / inclusive: f32[M] in the reference's Gaussian-major rect order (uitility.py:336-366); box_off:
@@ -306,10 +293,12 @@ int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, vo
  *   in depth order; mode 2: sum from this one to the deepest (grad_cumsum's flipped scan, gs_model.py:716-722).
  * Every pixel is scanned sequentially in depth order (the association of the CPU statement).  8 B / pair.  Feed the result
  * to gcp_compact_finish.  n_pairs = M = box_off[n_gauss], the length of x and inclusive (< 2^31; up to 2^30 the kernel
- * addresses pairs by 32-bit byte offsets). */
+ * addresses pairs by 32-bit byte offsets).  dropped_per_tile: NULL, or int32[ceil(n_pairs / 4096)] that receives, for
+ * every 4096 consecutive pairs, how many inclusive values are exactly 0 (integer adds, one per wave and list entry that
+ * has any: deterministic) — the per-tile counts gcp_compact_finish would otherwise read the array once more for. */
 int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                         float* inclusive, int64_t n_pairs, int32_t mode, void* stream);
+                         float* inclusive, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream);
 
 /* The rect list of the reference cut back into rectangles (gcp_pairs.hip), so that _create_alpha_brend / grad_cumsum can
  * take the tile-walk route (gcp_pairs_scan_boxes) from nothing but `rects` — which `_create_rects` always writes as a
@@ -336,9 +325,20 @@ int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t
 int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const int32_t* row_xy, int64_t n_rects, int64_t n,
                         int32_t* start_xy, int32_t* end_xy, int32_t* box_off, void* stream);
 
+/* The tail of _create_alpha_brend (gs_model.py:557-564) on the un-sorted inclusive scan values, elements [begin, end)
+ * of the original pair order (the reference's `cutting_number` slices, :557-559):
+ *   keep[j]   = inclusive[begin + j] != 0                                   (:560, :575-578)
+ *   values[k] = inclusive[i] / self[i] (mode 0, :562) or inclusive[i] - self[i] (mode 1, :564)
+ *               for the k-th kept i, in order                               (the boolean-mask compaction)
+ * count_dev[0] (device int32) receives the number of kept elements.  Stable stream compaction in two launches (per-tile
+ * counts, then ranks from one exclusive scan of them): no atomics, deterministic.  values needs room for end - begin
+ * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 21 B / element.
+ * dropped_per_tile: NULL, or what gcp_pairs_scan_boxes counted for THIS inclusive array (int32 per 4096 elements of
+ * the whole array, how many are exactly 0): the counting launch is then skipped (17 B / element); begin must be a
+ * multiple of 4096. */
 size_t gcp_compact_workspace_bytes(int64_t n);
 int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
-                       uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
+                       uint8_t* keep, int32_t* count_dev, const int32_t* dropped_per_tile, void* ws, size_t ws_bytes, void* stream);
 
 /* The index plumbing of _create_alpha_brend around the scan, with the int32 permutation of gcp_sort_pairs_u32:
  * gcp_gather_f32: dst[i] = src[index[i]] (gs_model.py:548); gcp_unsort_finish: full[index[i]] = inclusive[i] / x_i
@@ -358,6 +358,11 @@ int gcp_expand_rects(const int32_t* start_xy, const int32_t* end_xy, const int32
                      int64_t n_gauss, int64_t n_pairs, int32_t width, int32_t height,
                      int32_t* rects_xy, int32_t* pair_gauss /* may be NULL */, void* stream);
 
+/* f2, CSR export for callers of the scan API: per-pixel pair counts (row-major over the
+ * (H+1)x(W+1) image = ascending pixel key y*10000+x) and box sizes; then, given their exclusive
+ * prefix sums, pair_gauss[M] (Gaussian of every pair, pixel-major, depth order) and
+ * pair_index[M] (the pair's position in the reference's Gaussian-major rect list) — i.e. the
+ * `index` torch.sort(stable) returns at gs_model.py:547, bit for bit. */
 int gcp_pixel_lists_count(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss,
                           int32_t width, int32_t height, const int32_t* tile_start,
                           const int32_t* tile_list, int32_t* pixel_count, int32_t* box_size,

@@ -75,14 +75,14 @@ SIGNATURES = {
     "gcp_sort_rects": (ctypes.c_int, [_c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rects_key_range": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _c_void_p]),
     "gcp_compact_workspace_bytes": (_sz, [_i64]),
-    "gcp_compact_finish": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
+    "gcp_compact_finish": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rects_rows_workspace_bytes": (_sz, [_i64]),
     "gcp_rects_rows_capacity": (_i64, [_i64]),
     "gcp_rects_rows": (ctypes.c_int, [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rows_rectangles_workspace_bytes": (_sz, [_i64]),
     "gcp_rows_rectangles": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rectangle_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
-    "gcp_pairs_scan_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5 + [_i64, _i32, _c_void_p]),
+    "gcp_pairs_scan_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5 + [_i64, _i32, _c_void_p, _c_void_p]),
     "gcp_box_sizes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p]),
     "gcp_expand_rects": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _i64, _i32, _i32, _c_void_p, _c_void_p, _c_void_p]),
     "gcp_pixel_lists_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 5),

@@ -1034,12 +1034,32 @@ __device__ __forceinline__ void walk_load(WalkBatch& b, unsigned long long& hits
 #endif
   }
 }
-template <int MODE, bool WIDE>
-__device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict__ out, float& acc) {
+// COUNT: how many of the values just written are exactly 0 — what the `!= 0` compaction that follows drops
+// (gs_model.py:560) — per kCompactTile consecutive pairs.  One integer add per wave, list entry and tile that has any
+// (none at all in a scene without opaque or underflowing layers): the sums do not depend on the order.
+constexpr int kDropTileLog2 = 12;
+template <bool WIDE>
+__device__ __forceinline__ void walk_count_dropped(bool drop, unsigned off, int* __restrict__ dropped) {
+  unsigned long long dm = __ballot(drop);
+  if (!dm) return;
+  const unsigned blk = off >> (WIDE ? kDropTileLog2 : kDropTileLog2 + 2);
+  const int lane = (int)(threadIdx.x & 63);
+  while (dm) {
+    const int leader = __builtin_ctzll(dm);
+    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)blk, leader);
+    const unsigned long long same = __ballot(drop && blk == b);
+    if (lane == leader) atomicAdd(dropped + b, __builtin_popcountll(same));
+    dm &= ~same;
+  }
+}
+template <int MODE, bool WIDE, bool COUNT>
+__device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict__ out, float& acc, int* __restrict__ dropped) {
 #pragma unroll
   for (int u = 0; u < kWalkBatch; ++u) {
+    bool drop = false;
     if (b.in[u]) {
       acc = (MODE == 0) ? acc * b.v[u] : acc + b.v[u];
+      drop = acc == 0.0f;  // NaN is kept, as `!= 0` keeps it
 #if (GCP_WALK_DBG & 2)
       if (acc == 12345.678f)
 #endif
@@ -1048,13 +1068,14 @@ __device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict_
         else *(float*)((char*)out + b.off[u]) = acc;
       }
     }
+    if (COUNT) walk_count_dropped<WIDE>(drop, b.off[u], dropped);
   }
 }
 
-template <int MODE, bool WIDE>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
+template <int MODE, bool WIDE, bool COUNT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
-                                                          const float* __restrict__ x, float* __restrict__ out, int n_tiles,
-                                                          int xcd_remap) {
+                                                          const float* __restrict__ x, float* __restrict__ out,
+                                                          int* __restrict__ dropped, int n_tiles, int xcd_remap) {
   // a staged entry: x = position of the tile's first pixel in the entry's box run (box_off + (tile_y0 - y0) * width +
   // (tile_x0 - x0), may lie before the run), y = box width — both in bytes unless WIDE —, z = the box as bits over the
   // tile's columns (0-15) and rows (16-31).  A lane's pair is x + row * y + column, and it is in the box when both of
@@ -1112,12 +1133,12 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
       WalkBatch A, B;
       walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
       for (;;) {
-        if (!hits) { walk_fold<MODE, WIDE>(A, out, acc); break; }
+        if (!hits) { walk_fold<MODE, WIDE, COUNT>(A, out, acc, dropped); break; }
         walk_load<MODE, WIDE>(B, hits, s_ent, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE>(A, out, acc);
-        if (!hits) { walk_fold<MODE, WIDE>(B, out, acc); break; }
+        walk_fold<MODE, WIDE, COUNT>(A, out, acc, dropped);
+        if (!hits) { walk_fold<MODE, WIDE, COUNT>(B, out, acc, dropped); break; }
         walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE>(B, out, acc);
+        walk_fold<MODE, WIDE, COUNT>(B, out, acc, dropped);
       }
     }
   }
@@ -1192,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_rects_key_range(const int* rects, i64 n
 // the tile's kept count.  WRITE = true: every kept element's rank = tile offset (exclusive scan of the counts) + kept
 // elements before it in the tile (per-lane popcounts -> wave prefix in DPP -> 4 LDS words), its value written to that
 // slot — neighbouring lanes write neighbouring slots — and the mask as one packed word per lane.
-constexpr int kCompactTile = 4096;
+constexpr int kCompactTile = 1 << kDropTileLog2;
 template <bool VEC, bool WRITE>
 __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ incl, const float* __restrict__ self, i64 n, int mode,
                                                  int* __restrict__ cnt, const int* __restrict__ off, float* __restrict__ values,
@@ -1640,10 +1661,20 @@ size_t gcp_compact_workspace_bytes(int64_t n) {
   return align256((size_t)(nb + 1) * sizeof(int)) * 2 + gcp_scan_i32_workspace_bytes(nb);
 }
 
+// per-tile kept counts from the counts of dropped elements gcp_pairs_scan_boxes took while writing the array
+__global__ void k_counts_from_dropped(const int* __restrict__ dropped, i64 n, i64 nb, int* __restrict__ cnt) {
+  const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb) return;
+  const i64 len = n - t * kCompactTile;
+  cnt[t] = (int)(len < kCompactTile ? len : kCompactTile) - dropped[t];
+}
+
 int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,
-                       uint8_t* keep, int32_t* count_dev, void* ws, size_t ws_bytes, void* stream_) {
+                       uint8_t* keep, int32_t* count_dev, const int32_t* dropped_per_tile, void* ws, size_t ws_bytes,
+                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (begin < 0 || end < begin || end - begin > 0x7fffffffLL || (mode != 0 && mode != 1) || !count_dev) return GCP_ERR_INVALID_ARGUMENT;
+  if (dropped_per_tile && begin % kCompactTile != 0) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n = end - begin;
   if (n == 0) {
     GCP_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), stream));
@@ -1657,8 +1688,13 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
   int* off = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
   int* sws = (int*)p;
   const bool vec = (((uintptr_t)(inclusive + begin) | (uintptr_t)(self + begin) | (uintptr_t)keep) & 15u) == 0;
-  if (vec) hipLaunchKernelGGL((k_compact<true, false>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode, cnt,
-                              (const int*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
+  // (a last tile cut short by `end` gets a count that covers elements beyond it: never used — ranks come from the
+  // exclusive scan of the tiles before, the total from the write pass)
+  if (dropped_per_tile)
+    hipLaunchKernelGGL(k_counts_from_dropped, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream,
+                       dropped_per_tile + begin / kCompactTile, n, nb, cnt);
+  else if (vec) hipLaunchKernelGGL((k_compact<true, false>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode, cnt,
+                                   (const int*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
   else hipLaunchKernelGGL((k_compact<false, false>), dim3((unsigned)nb), dim3(256), 0, stream, inclusive + begin, self + begin, n, mode, cnt,
                           (const int*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
@@ -1674,24 +1710,34 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
 
 int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                         float* inclusive, int64_t n_pairs, int32_t mode, void* stream_) {
+                         float* inclusive, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
   if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2 || n_pairs < 0 || n_pairs > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
   if (n_gauss == 0 || n_pairs == 0) return GCP_OK;
   if (!start_xy || !end_xy || !tile_list || !box_off || !x || !inclusive || x == inclusive) return GCP_ERR_INVALID_ARGUMENT;
+  if (dropped_per_tile)
+    GCP_HIP(hipMemsetAsync(dropped_per_tile, 0, (size_t)((n_pairs + kCompactTile - 1) / kCompactTile) * sizeof(int), stream));
   const TileGrid tg = tile_grid(width, height);
   static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 1; }();
   // pair positions as 32-bit byte offsets while the list is no longer than 2^30 pairs (GCP_WALK_WIDE=1 forces the other form)
   const char* fw = getenv("GCP_WALK_WIDE");  // read per call: the tests switch it inside one process
   const bool wide = (fw && *fw && atoi(fw) != 0) || n_pairs > (1LL << 30);
+  const bool count = dropped_per_tile != nullptr;
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);
-#define GCP_WALK(M, W_) hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_>), grid, block, 0, stream, a, box_off, x, inclusive, n_tiles, xcd_remap)
-  if (mode == 0) { if (wide) GCP_WALK(0, true); else GCP_WALK(0, false); }
-  else if (mode == 1) { if (wide) GCP_WALK(1, true); else GCP_WALK(1, false); }
-  else { if (wide) GCP_WALK(2, true); else GCP_WALK(2, false); }
+#define GCP_WALK(M, W_, C_) \
+  hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, C_>), grid, block, 0, stream, a, box_off, x, inclusive, dropped_per_tile, n_tiles, xcd_remap)
+#define GCP_WALK_MODE(M)                                                    \
+  do {                                                                      \
+    if (wide) { if (count) GCP_WALK(M, true, true); else GCP_WALK(M, true, false); }  \
+    else { if (count) GCP_WALK(M, false, true); else GCP_WALK(M, false, false); }     \
+  } while (0)
+  if (mode == 0) GCP_WALK_MODE(0);
+  else if (mode == 1) GCP_WALK_MODE(1);
+  else GCP_WALK_MODE(2);
+#undef GCP_WALK_MODE
 #undef GCP_WALK
   GCP_HIP(hipGetLastError());
   return GCP_OK;

@@ -287,10 +287,11 @@ def _rects_as_boxes(rects, values, flag, cutting_number=None):
     if n != int(prep.shape[0]):
         raise RuntimeError(f"values: {n} rows, rects has {int(prep.shape[0])}")
     mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
-    inclusive = _raster.scan_boxes(bins, rb.start, rb.end, rb.box_off, values, mode)
+    # the walk counts the zeros it writes (per 4096 pairs): the compaction does not read the array once more to find them
+    inclusive, dropped = _raster.scan_boxes(bins, rb.start, rb.end, rb.box_off, values, mode, count_dropped=True)
     cut = int(cutting_number) if cutting_number else 0
     begin, end = (0, n - cut) if flag == "cumsum_reverse" else (cut, n)
-    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, begin, end)
+    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, begin, end, dropped=dropped)
     return [values_out, keep]
 
 
@@ -326,8 +327,8 @@ def _scan_boxes_compact(startpoint, endpoint, values, image_width, image_height,
     if values.numel() != m:
         raise RuntimeError(f"values: {values.numel()} rows, but the boxes expand to {m} pairs")
     mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
-    inclusive = _raster.scan_boxes(bins, startpoint, endpoint, box_off, values, mode)
-    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1)
+    inclusive, dropped = _raster.scan_boxes(bins, startpoint, endpoint, box_off, values, mode, count_dropped=True)
+    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, dropped=dropped)
     return [values_out, keep]
 
 

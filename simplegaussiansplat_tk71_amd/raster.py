@@ -281,11 +281,13 @@ def box_offsets(startpoint, endpoint, width, height):
         return exclusive_scan_i32(bsize[:n])
 
 
-def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
+def scan_boxes(bins, startpoint, endpoint, box_off, values, mode, count_dropped=False):
     """Inclusive per-pixel scan of `values` (f32[M], Gaussian-major rect order) in depth order, result in the same order:
     mode 0 product, 1 sum, 2 suffix sum — the sort / gather / scan / un-sort of _create_alpha_brend (gs_model.py:546-555)
     as one walk of the tile lists (gcp_pairs_scan_boxes).  Rows of `values` whose pair lies outside every listed box do
-    not exist by construction (box_off comes from the same boxes)."""
+    not exist by construction (box_off comes from the same boxes).  count_dropped: also return int32[ceil(M / 4096)], how
+    many results are exactly 0 in every 4096 consecutive pairs — hand it to `compact_finish(..., dropped=)`, which then
+    skips its counting launch."""
     start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
     end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
     x = _dev_tensor(values, "values", torch.float32)
@@ -293,14 +295,16 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode):
     _require(x.dim() == 1, "values: expected a 1-D tensor")
     _require(off.numel() == bins.n_gauss + 1, "box_off: expected n_gauss + 1 offsets")
     out = torch.empty_like(x)
+    dropped = torch.empty((x.numel() + 4095) // 4096, dtype=torch.int32, device=x.device) if count_dropped else None
     if x.numel() == 0 or bins.n_tile_pairs == 0:  # boxes that expand to nothing (all outside the image): nothing to scan
         _require(x.numel() == 0, "values: the boxes expand to no pair at all")
-        return out
+        return (out, dropped) if count_dropped else out
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().gcp_pairs_scan_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                                     bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
-                                                    out.data_ptr(), x.numel(), int(mode), _stream(x.device)), "gcp_pairs_scan_boxes")
-    return out
+                                                    out.data_ptr(), x.numel(), int(mode), dropped.data_ptr() if count_dropped else None,
+                                                    _stream(x.device)), "gcp_pairs_scan_boxes")
+    return (out, dropped) if count_dropped else out
 
 
 @dataclass
@@ -424,11 +428,12 @@ def sort_rects(rects, key_bits=None, image_size=None):
     return out_k, out_i
 
 
-def compact_finish(inclusive, self_values, mode, begin=0, end=None):
+def compact_finish(inclusive, self_values, mode, begin=0, end=None, dropped=None):
     """The tail of _create_alpha_brend (gs_model.py:557-564) on the un-sorted inclusive values, rows [begin, end):
     -> (values f32[n_kept] = inclusive / self (mode 0) or inclusive - self (mode 1) of the rows whose inclusive value is
     not 0, keep bool[end - begin]).  One device->host read (the kept count sizes the returned tensor, as the reference's
-    boolean-mask indexing does)."""
+    boolean-mask indexing does).  dropped: the per-4096 zero counts `scan_boxes(..., count_dropped=True)` took while it
+    wrote `inclusive` (used when begin is a multiple of 4096, ignored otherwise)."""
     inc = _dev_tensor(inclusive, "inclusive", torch.float32)
     sv = _dev_tensor(self_values, "self_values", torch.float32)
     _require(inc.dim() == 1 and sv.shape == inc.shape, "inclusive / self_values: expected two 1-D tensors of one length")
@@ -443,10 +448,16 @@ def compact_finish(inclusive, self_values, mode, begin=0, end=None):
         return values, keep.view(torch.bool)
     lib = _lib.load()
     count = torch.empty(1, dtype=torch.int32, device=dev)
+    if dropped is not None:
+        dropped = _dev_tensor(dropped, "dropped", torch.int32)
+        _require(dropped.numel() == (inc.numel() + 4095) // 4096, "dropped: expected one count per 4096 rows of `inclusive`")
+        if begin % 4096:
+            dropped = None
     with torch.cuda.device(dev):
         ws = torch.empty(lib.gcp_compact_workspace_bytes(n), dtype=torch.uint8, device=dev)
         _lib.check(lib.gcp_compact_finish(inc.data_ptr(), sv.data_ptr(), begin, end, int(mode), values.data_ptr(), keep.data_ptr(),
-                                          count.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gcp_compact_finish")
+                                          count.data_ptr(), dropped.data_ptr() if dropped is not None else None, ws.data_ptr(),
+                                          ws.numel(), _stream(dev)), "gcp_compact_finish")
     return values[: int(count.item())], keep.view(torch.bool)
 
 

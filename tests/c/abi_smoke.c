@@ -77,7 +77,7 @@ static int run_alpha_brend(void) {
   CHECK(gcp_sort_rects(d_r, n, 14 /* bits of 10003 */, 0, d_key, d_idx, ws_sort, b_sort, NULL));
   CHECK(gcp_workspace_init(ws_scan, b_scan, NULL));
   CHECK(gcp_cumprod_forward_indexed(d_a, (const int32_t*)d_key, d_idx, d_incl, n, ws_scan, b_scan, NULL));
-  CHECK(gcp_compact_finish(d_incl, d_a, 0, n, 0, d_val, d_keep, d_cnt, ws_cmp, b_cmp, NULL));
+  CHECK(gcp_compact_finish(d_incl, d_a, 0, n, 0, d_val, d_keep, d_cnt, NULL, ws_cmp, b_cmp, NULL));
   hipDeviceSynchronize();
   float incl[7], val[7]; uint8_t keep[7]; int32_t cnt = -1, idx[7]; uint32_t key[7];
   hipMemcpy(incl, d_incl, 28, 2); hipMemcpy(val, d_val, 28, 2); hipMemcpy(keep, d_keep, 7, 2); hipMemcpy(&cnt, d_cnt, 4, 2);

@@ -232,8 +232,8 @@ WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
     ("gcp_scan_main<3, true, false, true", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
     ("k_compact<true, false>", "compaction: count pass", 4, "both"),
     ("k_compact<true, true>", "compaction: write pass (mask + kept values)", 13, "both"),
-    ("k_pairs_scan_boxes<0>", "boxes route: tile-list walk, cumprod", 8, "boxes"),
-    ("k_pairs_scan_boxes<2>", "boxes route: tile-list walk, suffix sum", 8, "boxes"),
+    ("k_pairs_scan_boxes<0, false>", "boxes route: tile-list walk, cumprod", 8, "boxes"),
+    ("k_pairs_scan_boxes<2, false>", "boxes route: tile-list walk, suffix sum", 8, "boxes"),
 ]
 
 

@@ -200,8 +200,9 @@ WRAPPER_BYTES = {
     "indexed scan": {"sorted key": 4, "permutation": 4, "gathered value": 4, "scattered inclusive value": 4},
     "compaction": {"count pass reads the inclusive values": 4, "write pass reads inclusive + self": 8, "mask": 1, "kept values": 4},
 }
+# (the walk counts the zeros it writes, so this compaction has no counting pass)
 WRAPPER_BOX_BYTES = {"tile-list walk": {"value read": 4, "inclusive value written": 4},
-                     "compaction": {"count pass": 4, "write pass reads": 8, "mask": 1, "kept values": 4}}
+                     "compaction": {"write pass reads inclusive + self": 8, "mask": 1, "kept values": 4}}
 # the default route: the rect list cut back into rectangles (one read of the list; its row / rectangle records are ~1/13 of a
 # pair each, rounded up to 1 B/pair), then the boxes route
 WRAPPER_AUTO_BYTES = {"rect list -> rows -> rectangles": {"rects read once": 8, "row and rectangle records": 1}, **WRAPPER_BOX_BYTES}
@@ -270,7 +271,10 @@ def wrapper_level(dev, workload):
     t_bin = timed(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h))
     bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
     boff = raster.box_offsets(sc["start"], sc["end"], w, h)
-    t_walk = timed(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0))
+    t_walk = timed(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True))
+    incl_b, dropped = raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True)
+    t_comp_b = timed(lambda: raster.compact_finish(incl_b, anti, 0, dropped=dropped))
+    del incl_b, dropped
     b_rects = sum(sum(v.values()) for v in WRAPPER_BYTES.values())
     b_boxes = sum(sum(v.values()) for v in WRAPPER_BOX_BYTES.values())
     b_auto = sum(sum(v.values()) for v in WRAPPER_AUTO_BYTES.values())
@@ -298,7 +302,8 @@ def wrapper_level(dev, workload):
         "roofline": roof(b_auto, t_a5_auto),
         "with_prepared_rects_ms": {"create_alpha_brend": t_a5_prep, "grad_cumsum": t_a6_prep,
                                    "what": "cuda_kernel.PreparedRects(rects): cut + binning done once for the calls of one step"},
-        "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin, "tile-list walk": t_walk, "compact_finish": t_comp},
+        "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin,
+                      "tile-list walk (counts the zeros it writes)": t_walk, "compact_finish (no counting pass)": t_comp_b},
         "byte_model": WRAPPER_AUTO_BYTES,
         "general_sort_route": {
             "what": "route='sort': any list of pixel coordinates — key-in-sort stable radix sort, one indexed scan, the same compaction",
@@ -320,7 +325,8 @@ def wrapper_level(dev, workload):
             "create_alpha_brend_boxes_ms": t_a5b,
             "grad_cumsum_boxes_ms": t_a6b,
             "pairs_per_s": m / (t_a5b * 1e-3),
-            "stages_ms": {"bin_tiles": t_bin, "tile-list walk": t_walk, "compact_finish": t_comp},
+            "stages_ms": {"bin_tiles": t_bin, "tile-list walk (counts the zeros it writes)": t_walk,
+                          "compact_finish (no counting pass)": t_comp_b},
             "tile_entries": bins.n_tile_pairs,
             "roofline": roof(b_boxes, t_a5b),
             "byte_model": WRAPPER_BOX_BYTES,

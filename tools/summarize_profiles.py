@@ -230,10 +230,10 @@ WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
     ("k_sort_scatter2<false, false>", "sort passes 1, 2: scatter (per pass)", 16, "rects"),
     ("gcp_scan_main<0, true, false, true", "indexed scan, cumprod (gather + scan + un-sort)", 16, "rects"),
     ("gcp_scan_main<3, true, false, true", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
-    ("k_compact<true, false>", "compaction: count pass", 4, "both"),
+    ("k_compact<true, false>", "compaction: count pass (sort route only: the walk counts the zeros it writes)", 4, "rects"),
     ("k_compact<true, true>", "compaction: write pass (mask + kept values)", 13, "both"),
-    ("k_pairs_scan_boxes<0, false>", "boxes route: tile-list walk, cumprod", 8, "boxes"),
-    ("k_pairs_scan_boxes<2, false>", "boxes route: tile-list walk, suffix sum", 8, "boxes"),
+    ("k_pairs_scan_boxes<0, false, true>", "tile-list walk, cumprod (counts the zeros it writes)", 8, "boxes"),
+    ("k_pairs_scan_boxes<2, false, true>", "tile-list walk, suffix sum (counts the zeros it writes)", 8, "boxes"),
 ]
 
 

@@ -98,8 +98,11 @@ def main():
             bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
             st["boxes_box_offsets_ms"] = timeit(lambda: raster.box_offsets(sc["start"], sc["end"], w, h), iters)
             boff = raster.box_offsets(sc["start"], sc["end"], w, h)
-            st["boxes_walk_cumprod_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0), iters)
-            st["boxes_walk_reverse_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, grad, 2), iters)
+            st["boxes_walk_cumprod_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True), iters)
+            st["boxes_walk_reverse_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, grad, 2, count_dropped=True), iters)
+            incl_b, dropped = raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True)
+            st["boxes_compact_finish_ms"] = timeit(lambda: raster.compact_finish(incl_b, anti, 0, dropped=dropped), iters)
+            del incl_b, dropped
             st["tile_entries"] = bins.n_tile_pairs
             del bins, boff
             y = torch.empty_like(anti)

@@ -332,9 +332,9 @@ int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const
  *               for the k-th kept i, in order                               (the boolean-mask compaction)
  * count_dev[0] (device int32) receives the number of kept elements.  Stable stream compaction in two launches (per-tile
  * counts, then ranks from one exclusive scan of them): no atomics, deterministic.  values needs room for end - begin
- * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 21 B / element.
+ * floats.  ws: gcp_compact_workspace_bytes(end - begin).  Traffic: 17 B / element.
  * dropped_per_tile: NULL, or what gcp_pairs_scan_boxes counted for THIS inclusive array (int32 per 4096 elements of
- * the whole array, how many are exactly 0): the counting launch is then skipped (17 B / element); begin must be a
+ * the whole array, how many are exactly 0): the counting launch is then skipped (13 B / element); begin must be a
  * multiple of 4096. */
 size_t gcp_compact_workspace_bytes(int64_t n);
 int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin, int64_t end, int32_t mode, float* values,

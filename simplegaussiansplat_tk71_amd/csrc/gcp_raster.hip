@@ -988,9 +988,9 @@ constexpr int kWalkStage = 64;  // list entries staged per round: one hit word p
 #define GCP_WALK_BATCH 8
 #endif
 #ifndef GCP_WALK_DBG
-#define GCP_WALK_DBG 0
+#define GCP_WALK_DBG 0  // measurement builds only (tools/build_variant.py): 1 = no loads, 2 = no stores — DESIGN.md §3.4's split
 #endif
-constexpr int kWalkBatch = GCP_WALK_BATCH;  // listed entries whose loads are in flight together (a power of two)
+constexpr int kWalkBatch = GCP_WALK_BATCH;  // listed entries whose loads are in flight together
 
 // A batch: kWalkBatch listed entries of one wave's hit word.  The staged records are read together and the values
 // loaded together (walk_load); walk_fold then multiplies / adds them in list order and stores the running values.

@@ -305,9 +305,12 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
  * concatenation of row-major boxes (gs_model.py:480-482, uitility.py:336-366).  Valid for ANY list: a list that is not made
  * of boxes yields about as many rectangles as elements, and the caller then sorts instead.
  *   gcp_rects_rows: rows = maximal runs (x, y), (x+1, y), ...  row_start[k] = index of the k-th row's first element,
- *     row_start[rows] = n, row_xy[k] = its (x, y); both need room for gcp_rects_rows_capacity(n) entries.  info (device
- *     int32[5]) = {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: some 4096-element stretch holds more than
- *     1024 rows (or a coordinate does not fit x < 2^14, y < 2^17) — the outputs are then incomplete, sort instead.
+ *     row_start[rows] = n, row_xy[k] = its (x, y); both have room for row_capacity entries.  info (device int32[5]) =
+ *     {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: the list has more than row_capacity - 1 rows (or a
+ *     coordinate does not fit x < 2^14, y < 2^17) — nothing was written, sort instead.  gcp_rects_rows_capacity(n) = n / 2 + 2
+ *     is what a list of boxes is allowed; a caller whose list starts or ends with c single-pixel carry rows (the
+ *     `cutting_number` rows of gs_model.py:611, :636 — lexicographically sorted unique pixels: they come out as one-pixel-wide
+ *     rectangles) passes c + gcp_rects_rows_capacity(n - c).
  *   gcp_rows_rectangles: rectangles = maximal runs of rows with equal first x and length and y growing by one.
  *     rect_row[b] = first row of rectangle b (room for n_rows + 1 entries; rect_row[rectangles] = n_rows).  info (device
  *     int32[2]) = {rectangles, 0}.

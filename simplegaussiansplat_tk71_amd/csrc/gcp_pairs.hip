@@ -33,7 +33,8 @@ using namespace gcp;
 
 constexpr int kRowsPerThread = 4;                 // 16 elements per thread
 constexpr int kElemTile = 1024 * kRowsPerThread;  // 4096 elements per block
-constexpr int kSlotRows = 1024;                   // row records a tile may park: a list of boxes needs ~ 4096 / box width
+constexpr int kSlotRows = kElemTile;              // row records a tile may park: every element may start a row (the carry rows of a
+                                                  // chunked call, gs_model.py:611, are single pixels); a list of boxes parks ~ 4096 / box width
 constexpr int kRowTile = 1024;                    // rows per block in the second cut, 4 per thread
 
 // Ranks of the set bits of m[0..ROWS) inside the block: thread t of wave w holds the flags of the 4 consecutive items
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if ((m[r] >> k) & 1u) {
-        if (o < kSlotRows) mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+        mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
         ++o;
       }
     }
@@ -123,8 +124,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
   if (lane == 0) { s_mx[w] = mx; s_my[w] = my; s_mn[w] = mn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    cnt[tile] = min(count, kSlotRows);
-    if (count > kSlotRows) info[4] = 1;  // rows shorter than 4 on average here: not a list of boxes
+    cnt[tile] = count;
     // Look before the atomic: 40 000 blocks hitting three words with an atomic each serialise at the L2 (1.1 of this
     // kernel's 1.4 ms when first written that way); the range settles after the first few blocks and the rest only read.
     const int bx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])), by = max(max(s_my[0], s_my[1]), max(s_my[2], s_my[3]));
@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
 
 // ---- cut 1, pass 2: the parked records to their final places -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
-                                                          i64 n_tiles, int* __restrict__ row_start, int2* __restrict__ row_xy,
-                                                          int* __restrict__ info) {
+                                                          i64 n_tiles, i64 row_capacity, int* __restrict__ row_start,
+                                                          int2* __restrict__ row_xy, int* __restrict__ info) {
   const i64 tile = blockIdx.x;
+  if ((i64)off[n_tiles] + 1 > row_capacity) {  // more rows than the caller made room for: not a list of boxes, nothing is written
+    if (tile == 0 && threadIdx.x == 0) { info[0] = off[n_tiles]; info[4] = 1; }
+    return;
+  }
   const int o0 = off[tile], c = off[tile + 1] - o0;
   const int2* const mine = slots + tile * kSlotRows;
   for (int i = threadIdx.x; i < c; i += 256) {
@@ -230,8 +234,6 @@ int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int
   if (!rects_xy || !row_start || !row_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
   if (ws_bytes < gcp_rects_rows_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
-  // every tile can deliver kSlotRows rows: the caller's arrays must hold them all (+ the sentinel), or nothing is written
-  if (row_capacity < n_tiles * (i64)kSlotRows + 1 && row_capacity < n + 1) return GCP_ERR_INVALID_ARGUMENT;
   char* p = (char*)ws;
   int2* slots = (int2*)p; p += align256((size_t)n_tiles * kSlotRows * sizeof(int2));
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
@@ -241,16 +243,15 @@ int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
   hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, (const int*)off, (i64)n, n_tiles,
-                     row_start, (int2*)row_xy, info);
+                     (i64)row_capacity, row_start, (int2*)row_xy, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
 
-int64_t gcp_rects_rows_capacity(int64_t n) {
-  const int64_t t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
-  const int64_t a = t * kSlotRows + 1, b = (n > 0 ? n : 0) + 1;
-  return a < b ? a : b;
-}
+// rows a list may have and still be taken for boxes: a list of boxes has ~ n / (box width) of them, a list of unrelated
+// coordinates ~ n; the line is drawn at one row per two elements (whether the rectangles are worth walking is the
+// caller's second test, on their count)
+int64_t gcp_rects_rows_capacity(int64_t n) { return (n > 0 ? n : 0) / 2 + 2; }
 
 size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows) {
   const int64_t t = (n_rows > 0 ? n_rows + kRowTile - 1 : kRowTile) / kRowTile;

@@ -261,13 +261,15 @@ class PreparedRects:
         T, mask = create_alpha_brend(prep, anti_opacity, "cumprod")
         S, mask = grad_cumsum(prep, grad)
 
-    `boxes` is None when the list is not a concatenation of boxes; the calls then sort (`rects` is kept for that)."""
+    `boxes` is None when the list is not a concatenation of boxes; the calls then sort (`rects` is kept for that).
+    carry_rows: the number of `cutting_number` rows the list starts (or, for `grad_cumsum`, ends) with in a chunked call
+    (gs_model.py:611, :636): single pixels, which are cut into one-pixel-wide rectangles and walked like the boxes."""
 
-    def __init__(self, rects):
+    def __init__(self, rects, carry_rows=0):
         self.rects = rects
         self.shape = rects.shape
         with torch.no_grad():
-            rb = _raster.rects_to_boxes(rects)
+            rb = _raster.rects_to_boxes(rects, carry_rows=carry_rows)
             if rb is not None and (rb.width + 1) * (rb.height + 1) > _MAX_WALK_PIXELS:
                 rb = None
             self.boxes = rb
@@ -278,7 +280,7 @@ def _rects_as_boxes(rects, values, flag, cutting_number=None):
     """The boxes route from nothing but the rect list; None if the list is not a concatenation of boxes."""
     if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
         raise ValueError(flag)
-    prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects)
+    prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects, carry_rows=int(cutting_number) if cutting_number else 0)
     rb, bins = prep.boxes, prep.bins
     if rb is None:
         return None

@@ -317,11 +317,13 @@ class RectBoxes:
     height: int            # largest y
 
 
-def rects_to_boxes(rects, min_mean_size=8):
+def rects_to_boxes(rects, min_mean_size=8, carry_rows=0):
     """Cut the reference's rect list (int [M,2] (x, y), gs_model.py:480-482) back into the row-major rectangles it is a
     concatenation of (csrc/gcp_pairs.hip).  Works on any list; returns None when the list does not look like boxes at all
-    (fewer than `min_mean_size` pairs per rectangle on average, or a stretch of 4096 pairs with more than 1024 rows: the
-    caller sorts instead).  Two device->host reads (row and rectangle counts)."""
+    (more than one row per two pairs, or fewer than `min_mean_size` pairs per rectangle on average: the caller sorts
+    instead).  carry_rows: how many single-pixel carry rows the list starts or ends with (a chunked call's
+    `cutting_number` rows, gs_model.py:611, :636 — sorted unique pixels, which come out as one-pixel-wide rectangles): they
+    are allowed for on top.  Two device->host reads (row and rectangle counts)."""
     r = _dev_tensor(rects, "rects", torch.int32, (2,))
     m = r.size(0)
     dev = r.device
@@ -329,7 +331,8 @@ def rects_to_boxes(rects, min_mean_size=8):
         z = torch.zeros(0, 2, dtype=torch.int32, device=dev)
         return RectBoxes(z, z.clone(), torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
     lib = _lib.load()
-    cap = lib.gcp_rects_rows_capacity(m)
+    carry_rows = min(max(int(carry_rows), 0), m)
+    cap = min(carry_rows + lib.gcp_rects_rows_capacity(m - carry_rows), m + 1)
     with torch.cuda.device(dev):
         st = _stream(dev)
         row_start = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -341,7 +344,7 @@ def rects_to_boxes(rects, min_mean_size=8):
         n_rows, max_x, max_y, mn, not_boxes = info.tolist()
         del ws
         _require(mn >= 0, "rects: negative coordinates are not supported")
-        if not_boxes:  # some stretch of the list has rows shorter than 4 on average: the general route
+        if not_boxes:  # rows shorter than 2 pairs on average (the carry rows apart): the general route
             return None
         rect_row = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
         info2 = torch.empty(2, dtype=torch.int32, device=dev)

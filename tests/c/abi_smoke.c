@@ -99,7 +99,7 @@ static int run_alpha_brend(void) {
 static int run_rect_cut(void) {
   const int64_t n = 7;
   const int32_t rects[14] = {1, 1, 2, 1, 1, 1, 2, 1, 3, 1, 1, 1, 3, 1};
-  const int64_t cap = gcp_rects_rows_capacity(n);
+  const int64_t cap = gcp_rects_rows_capacity(n) + n;  /* seven pairs in four rows: more rows than a list of boxes is allowed */
   int32_t *d_r, *d_rs, *d_rxy, *d_info, *d_rr, *d_info2, *d_s, *d_e, *d_off; void *ws1, *ws2;
   const size_t b1 = gcp_rects_rows_workspace_bytes(n);
   if (hipMalloc((void**)&d_r, 56) || hipMalloc((void**)&d_rs, cap * 4) || hipMalloc((void**)&d_rxy, cap * 8) || hipMalloc((void**)&d_info, 20) ||

@@ -100,6 +100,45 @@ def test_wrappers_small_scenes_and_cutting_number(device, n_gauss, w, h, mh, see
         torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4, rtol=TOL)
 
 
+@pytest.mark.parametrize("flag", ["cumprod", "cumsum", "grad_cumsum"])
+def test_chunked_calls_with_carry_rows_take_the_walk(device, flag):
+    """The reference's second and later chunks call `_create_alpha_brend(cat(unique_rects, rects), cat(T_min, anti),
+    cutting_number=len(unique_rects))` (gs_model.py:611-612; `grad_cumsum` with the carry rows at the END, :636): the carry
+    rows are the lexicographically sorted unique pixels of the chunks before (torch.unique(dim=0), :584).  Such a list is
+    still cut into rectangles — the carry pixels come out as one-pixel-wide columns — and walked; results against the CPU
+    statement, and bit-equal masks."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(2500, 200, 120, 9, 17)
+    rects, _ = _rects_of(sc, device)
+    half = rects.size(0) // 2  # the carry rows of a second chunk: the unique pixels the first chunk touched
+    unique_rects = torch.unique(rects[:half], dim=0)
+    c = unique_rects.size(0)
+    g = torch.Generator().manual_seed(4)
+    chunk = rects[half:]
+    if flag == "grad_cumsum":
+        lst = torch.cat([chunk, unique_rects])
+        vals = torch.randn(lst.size(0), generator=g)
+    else:
+        lst = torch.cat([unique_rects, chunk])
+        vals = 1.0 - 0.95 * torch.rand(lst.size(0), generator=g)
+        vals[c::17] = 0.0
+    assert c > lst.size(0) // 8  # a sizeable part of the list is single pixels
+    assert raster.rects_to_boxes(lst, carry_rows=c) is not None
+    for route in ("auto", "boxes", "sort"):
+        if flag == "grad_cumsum":
+            v, k = ck.grad_cumsum(lst, vals.to(device), c, route=route)
+            wv, wk_flipped = ow.grad_cumsum(lst.cpu(), vals, c)
+            wk = wk_flipped.flip(0)
+        else:
+            v, k = ck.create_alpha_brend(lst, vals.to(device), flag, c, route=route)
+            wv, wk, _, _ = ow.create_alpha_brend(lst.cpu(), vals, flag, c)
+        assert torch.equal(k.cpu(), wk), route
+        torch.testing.assert_close(v.cpu(), wv, atol=1e-4 if flag != "cumprod" else TOL, rtol=TOL)
+
+
 @pytest.mark.parametrize("n,wmax,hmax", [(1, 3, 3), (63, 7, 5), (4096, 1919, 1079), (4097, 50, 50), (100003, 1919, 1079),
                                         (3_000_017, 3839, 2159), (50_000, 0, 0), (1_000_000, 9999, 200_000),
                                         # 2, 3 and 5 chunks per block (the super-chunk length grows with n up to 8 at 6.7e7 keys)
@@ -490,7 +529,7 @@ def test_rects_to_boxes_on_lists_that_are_not_boxes(device):
     torch.testing.assert_close(a_v.cpu(), w_v, atol=TOL, rtol=TOL)
     with pytest.raises(RuntimeError, match="boxes"):
         ck.create_alpha_brend(rnd.to(device), anti.to(device), "cumprod", route="boxes")
-    assert raster.rects_to_boxes(rnd.to(device), min_mean_size=0) is None  # > 1024 rows in 4096 elements: refused outright
+    assert raster.rects_to_boxes(rnd.to(device), min_mean_size=0) is None  # about one row per element: refused outright
     # random one-row pieces of 6 pixels: cut correctly (every piece a rectangle), but too small to be worth the walk
     x0 = torch.randint(0, 190, (8000,), generator=g)
     y0 = torch.randint(0, 150, (8000,), generator=g)

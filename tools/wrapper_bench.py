@@ -3,7 +3,7 @@ sizes: whole-call times of create_alpha_brend(rects), create_alpha_brend_boxes, 
 stage of the rects route timed on its own.  Run it under `rocprofv3 --kernel-trace --stats` for the kernel table that
 profiles/r03_wrappers.md quotes.
 
-  python tools/wrapper_bench.py [cfg2 cfg3] [--stages] [--iters 5]
+  python tools/wrapper_bench.py [cfg2 cfg3] [--stages] [--chunked] [--iters 5]
 """
 import json
 import os
@@ -79,6 +79,18 @@ def main():
         out["sort_route_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", route="sort"), iters)
         out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
         out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
+        if "--chunked" in argv:
+            # a second chunk's call (gs_model.py:611-612): the image's pixels as carry rows in torch.unique's order, then the boxes
+            xs = torch.arange(w + 1, device=dev, dtype=torch.int32)
+            ys = torch.arange(h + 1, device=dev, dtype=torch.int32)
+            carry = torch.stack([xs[:, None].expand(-1, h + 1).reshape(-1), ys[None, :].expand(w + 1, -1).reshape(-1)], 1)
+            c = carry.size(0)
+            lst = torch.cat([carry, rects])
+            vals = torch.cat([torch.rand(c, device=dev) * 0.5 + 0.5, anti])
+            out["chunked_call_carry_rows"] = c
+            out["chunked_call_create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(lst, vals, "cumprod", c), iters)
+            out["chunked_call_sort_route_ms"] = timeit(lambda: ck.create_alpha_brend(lst, vals, "cumprod", c, image_size=(w, h), route="sort"), iters)
+            del lst, vals, carry
         if stages:
             import grouped_cumprod as gc
 

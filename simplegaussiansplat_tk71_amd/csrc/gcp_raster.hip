@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
         const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
         rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
         // modulo 2^32: every pair of the list lies below 2^32 bytes (2^31 pairs when WIDE), whatever the tile's corner does
-        const unsigned p0 = (unsigned)box_off[g] + (unsigned)((tile_y0 - b.y0) * wd + (tile_x0 - b.x0));
+        const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 - b.x0);
         s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(cm | (rm << 16)), 0);
       }
 #pragma unroll

@@ -1680,7 +1680,7 @@ size_t gcp_compact_workspace_bytes(int64_t n) {
 }
 
 // per-tile kept counts from the counts of dropped elements gcp_pairs_scan_boxes took while writing the array
-__global__ void k_counts_from_dropped(const int* __restrict__ dropped, i64 n, i64 nb, int* __restrict__ cnt) {
+static __global__ void k_counts_from_dropped(const int* __restrict__ dropped, i64 n, i64 nb, int* __restrict__ cnt) {
   const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb) return;
   const i64 len = n - t * kCompactTile;

@@ -147,3 +147,27 @@ def test_streaming_scan_kernels_hold_their_registers_without_scratch(tmp_path):
     assert len(kernels) >= 16
     bad = [(k, scratch, spills) for k, scratch, spills in kernels if int(scratch) or int(spills)]
     assert not bad, bad
+
+
+def test_walk_compaction_and_blend_kernels_use_no_scratch(tmp_path):
+    """The same for the kernels of rows a5 / a6 and f1: the tile-list walk holds two batches of eight pairs in registers
+    (67-79 VGPRs), the compaction's write pass 16 elements per thread (77), the fused blend backward 75."""
+    import re
+    import subprocess
+
+    from simplegaussiansplat_tk71_amd import _build
+
+    src = [s for s in _build.SRCS if s.endswith("gcp_raster.hip")][0]
+    out = tmp_path / "raster.s"
+    flags = [f for f in _build.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    res = subprocess.run([_build.find_hipcc(), *flags, "-I", _build.INCLUDE, "-S", "--cuda-device-only", "-o", str(out), src],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+    seen = {frag: [k for k in kernels if frag in k[0]] for frag in ("k_pairs_scan_boxes", "k_compact", "k_blend_bwd", "k_blend_fwd", "k_sort_scatter2")}
+    assert len(seen["k_pairs_scan_boxes"]) == 12 and len(seen["k_compact"]) == 4 and all(seen.values())
+    bad = [(k, scratch, spills) for k, scratch, _, spills in kernels if int(scratch) or int(spills)]
+    assert not bad, bad
+    # eight waves per SIMD need <= 64 VGPRs, six <= 80: nothing on these paths may slip under six
+    assert max(int(v) for ks in seen.values() for _, _, v, _ in ks) <= 80

@@ -1073,6 +1073,7 @@ __device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict_
 }
 
 template <int MODE, bool WIDE, bool COUNT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
+// (pinned to eight waves per SIMD the byte-offset form fits 63 VGPRs without a spill — and runs no faster: 0.62 ms either way)
 __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
                                                           const float* __restrict__ x, float* __restrict__ out,
                                                           int* __restrict__ dropped, int n_tiles, int xcd_remap) {

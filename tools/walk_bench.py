@@ -31,6 +31,7 @@ def main():
                "tile_entries": bins.n_tile_pairs}
         for name, vals, mode in (("cumprod", anti, 0), ("cumsum", anti, 1), ("reverse", grad, 2)):
             out[name + "_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, vals, mode), iters, 3)
+            out[name + "_counting_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, vals, mode, count_dropped=True), iters, 3)
         out["checksum"] = float(ref.double().sum())
         print(json.dumps(out), flush=True)
 

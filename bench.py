@@ -251,6 +251,10 @@ def wrapper_level(dev, workload):
     t_a5_auto = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters=7, warmup=4, warm_s=0.1)
     t_a6_auto = timed(lambda: ck.grad_cumsum(rects, grad), iters=7, warmup=2)
     t_cut = timed(lambda: raster.rects_to_boxes(rects))
+    # the dtype the reference's own make_rect_points_parallel returns (uitility.py:336-366): int64, 16 B per pair, read as it is
+    rects64 = rects.long()
+    t_a5_i64 = timed(lambda: ck.create_alpha_brend(rects64, anti, "cumprod"))
+    del rects64
     prep = ck.PreparedRects(rects)  # cut + binning once for the forward's and the backward's call on the same list
     t_a5_prep = timed(lambda: ck.create_alpha_brend(prep, anti, "cumprod"))
     t_a6_prep = timed(lambda: ck.grad_cumsum(prep, grad))
@@ -305,6 +309,7 @@ def wrapper_level(dev, workload):
         "route": "auto -> boxes: the rect list (a concatenation of row-major boxes, uitility.py:336-366) is cut back into rectangles, "
                  "binned into tiles and walked; no M-sized sort",
         "roofline": roof(b_auto, t_a5_auto),
+        "create_alpha_brend_int64_rects_ms": t_a5_i64,
         "with_prepared_rects_ms": {"create_alpha_brend": t_a5_prep, "grad_cumsum": t_a6_prep,
                                    "what": "cuda_kernel.PreparedRects(rects): cut + binning done once for the calls of one step"},
         "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin,

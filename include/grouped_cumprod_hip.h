@@ -322,6 +322,11 @@ size_t gcp_rects_rows_workspace_bytes(int64_t n);
 int64_t gcp_rects_rows_capacity(int64_t n);
 int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
                    void* ws, size_t ws_bytes, void* stream);
+/* The same on a list of int64 coordinates — the dtype the reference's own make_rect_points_parallel returns
+ * (uitility.py:336-366: `start + ix`, ix from torch.arange): read where it lies instead of being narrowed by a pass of its
+ * own.  A coordinate outside [0, 2^31) is reported as a negative minimum (info[3] < 0). */
+int gcp_rects_rows_i64(const int64_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
+                       void* ws, size_t ws_bytes, void* stream);
 size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows);
 int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
                         size_t ws_bytes, void* stream);

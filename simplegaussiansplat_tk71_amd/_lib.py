@@ -79,6 +79,7 @@ SIGNATURES = {
     "gcp_rects_rows_workspace_bytes": (_sz, [_i64]),
     "gcp_rects_rows_capacity": (_i64, [_i64]),
     "gcp_rects_rows": (ctypes.c_int, [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
+    "gcp_rects_rows_i64": (ctypes.c_int, [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rows_rectangles_workspace_bytes": (_sz, [_i64]),
     "gcp_rows_rectangles": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rectangle_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -62,7 +62,20 @@ __device__ __forceinline__ int block_ranks(const unsigned (&m)[ROWS], int (&rank
 }
 
 // ---- cut 1, pass 1: row starts of one tile -> the tile's slots; count; coordinate range ---------------------------------
-__global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict__ rects, i64 n, int2* __restrict__ slots /*[tiles][kSlotRows]: {index, x | y << 14}*/,
+// One (x, y) of the list as int32s.  I64: the list holds int64 coordinates — what the reference's own
+// make_rect_points_parallel returns (uitility.py:336-366: `start + ix` with ix from torch.arange) — read where they lie, 16
+// bytes per element, instead of being converted by a pass of its own; a coordinate outside [0, 2^31) comes back as -1 and
+// the list is refused like any with negative coordinates.
+template <bool I64>
+__device__ __forceinline__ int2 rect_at(const void* __restrict__ rects, i64 i) {
+  if (!I64) return reinterpret_cast<const int2*>(rects)[i];
+  const longlong2 q = reinterpret_cast<const longlong2*>(rects)[i];
+  const bool ok = ((unsigned long long)q.x | (unsigned long long)q.y) < 0x80000000ull;
+  return ok ? make_int2((int)q.x, (int)q.y) : make_int2(-1, -1);
+}
+
+template <bool I64>
+__global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, int2* __restrict__ slots /*[tiles][kSlotRows]: {index, x | y << 14}*/,
                                                          int* __restrict__ cnt, int* __restrict__ info /*[5]: rows, max x, max y, min, overflow*/) {
   __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -73,15 +86,15 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
   int mx = 0, my = 0, mn = 0x7fffffff;
   const bool vec = (((uintptr_t)rects) & 15u) == 0;
 #pragma unroll
-  for (int r = 0; r < kRowsPerThread; ++r) {  // all loads of the lane first: two 16-byte loads per row where the row is whole
+  for (int r = 0; r < kRowsPerThread; ++r) {  // all loads of the lane first: 16-byte loads where the row is whole
     const i64 p = base + r * 256 + lane * 4;
-    if (vec && p + 3 < n) {
-      const int4 a = *reinterpret_cast<const int4*>(rects + p);
-      const int4 b = *reinterpret_cast<const int4*>(rects + p + 2);
+    if (!I64 && vec && p + 3 < n) {
+      const int4 a = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(rects) + p);
+      const int4 b = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(rects) + p + 2);
       e[r][0] = make_int2(a.x, a.y); e[r][1] = make_int2(a.z, a.w); e[r][2] = make_int2(b.x, b.y); e[r][3] = make_int2(b.z, b.w);
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) e[r][k] = (p + k < n) ? rects[p + k] : make_int2(0x7ffffff0, 0x7ffffff0);
+      for (int k = 0; k < 4; ++k) e[r][k] = (p + k < n) ? rect_at<I64>(rects, p + k) : make_int2(0x7ffffff0, 0x7ffffff0);
     }
   }
 #pragma unroll
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const int2* __restrict_
     int2 prev;
     prev.x = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].x);
     prev.y = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].y);
-    if (lane == 0) prev = (p > 0 && p <= n) ? rects[p - 1] : make_int2(0x7ffffff0, 0x7ffffff0);  // (nothing continues the first element)
+    if (lane == 0) prev = (p > 0 && p <= n) ? rect_at<I64>(rects, p - 1) : make_int2(0x7ffffff0, 0x7ffffff0);  // (nothing continues the first element)
     m[r] = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -224,8 +237,8 @@ size_t gcp_rects_rows_workspace_bytes(int64_t n) {
   return align256((size_t)t * kSlotRows * sizeof(int2)) + 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
 }
 
-int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
-                   void* ws, size_t ws_bytes, void* stream_) {
+static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy,
+                           int32_t* info, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || n > 0x7fffffffLL || row_capacity < 1 || !info) return GCP_ERR_INVALID_ARGUMENT;
   GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), overflow
@@ -238,7 +251,8 @@ int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int
   int2* slots = (int2*)p; p += align256((size_t)n_tiles * kSlotRows * sizeof(int2));
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
-  hipLaunchKernelGGL(k_rect_rows_local, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)rects_xy, (i64)n, slots, cnt, info);
+  if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, slots, cnt, info);
+  else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, slots, cnt, info);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
@@ -246,6 +260,16 @@ int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int
                      (i64)row_capacity, row_start, (int2*)row_xy, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
+}
+
+int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
+                   void* ws, size_t ws_bytes, void* stream) {
+  return rects_rows_impl(rects_xy, false, n, row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
+}
+
+int gcp_rects_rows_i64(const int64_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
+                       void* ws, size_t ws_bytes, void* stream) {
+  return rects_rows_impl(rects_xy, true, n, row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
 }
 
 // rows a list may have and still be taken for boxes: a list of boxes has ~ n / (box width) of them, a list of unrelated

@@ -324,13 +324,16 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0):
     instead).  carry_rows: how many single-pixel carry rows the list starts or ends with (a chunked call's
     `cutting_number` rows, gs_model.py:611, :636 — sorted unique pixels, which come out as one-pixel-wide rectangles): they
     are allowed for on top.  Two device->host reads (row and rectangle counts)."""
-    r = _dev_tensor(rects, "rects", torch.int32, (2,))
+    # int64 lists — what the reference's own make_rect_points_parallel returns (uitility.py:336-366) — are read as they are
+    i64 = isinstance(rects, torch.Tensor) and rects.dtype == torch.int64
+    r = _dev_tensor(rects, "rects", torch.int64 if i64 else torch.int32, (2,))
     m = r.size(0)
     dev = r.device
     if m == 0:
         z = torch.zeros(0, 2, dtype=torch.int32, device=dev)
         return RectBoxes(z, z.clone(), torch.zeros(1, dtype=torch.int32, device=dev), 0, 0)
     lib = _lib.load()
+    cut = lib.gcp_rects_rows_i64 if i64 else lib.gcp_rects_rows
     carry_rows = min(max(int(carry_rows), 0), m)
     cap = min(carry_rows + lib.gcp_rects_rows_capacity(m - carry_rows), m + 1)
     with torch.cuda.device(dev):
@@ -339,11 +342,11 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0):
         row_xy = torch.empty(cap, 2, dtype=torch.int32, device=dev)
         info = torch.empty(5, dtype=torch.int32, device=dev)
         ws = torch.empty(lib.gcp_rects_rows_workspace_bytes(m), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gcp_rects_rows(r.data_ptr(), m, cap, row_start.data_ptr(), row_xy.data_ptr(), info.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), st), "gcp_rects_rows")
+        _lib.check(cut(r.data_ptr(), m, cap, row_start.data_ptr(), row_xy.data_ptr(), info.data_ptr(), ws.data_ptr(),
+                       ws.numel(), st), "gcp_rects_rows")
         n_rows, max_x, max_y, mn, not_boxes = info.tolist()
         del ws
-        _require(mn >= 0, "rects: negative coordinates are not supported")
+        _require(mn >= 0, "rects: coordinates must lie in [0, 2^31) (negative ones are not supported)")
         if not_boxes:  # rows shorter than 2 pairs on average (the carry rows apart): the general route
             return None
         rect_row = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)

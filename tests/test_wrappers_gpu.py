@@ -100,6 +100,41 @@ def test_wrappers_small_scenes_and_cutting_number(device, n_gauss, w, h, mh, see
         torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4, rtol=TOL)
 
 
+def test_int64_rect_lists_are_read_as_they_are(device):
+    """The reference's own rect lists are int64 (`start + ix` with ix from torch.arange, uitility.py:336-366): the cut reads
+    them where they lie (gcp_rects_rows_i64) — same boxes, same results as from the int32 copy, unaligned views included;
+    a coordinate that does not fit int32 is refused."""
+    import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(3000, 300, 200, 12, 4)
+    rects, _ = _rects_of(sc, device)
+    m = rects.size(0)
+    g = torch.Generator().manual_seed(1)
+    anti = (1.0 - 0.95 * torch.rand(m, generator=g)).to(device)
+    anti[::13] = 0.0
+    grad = torch.randn(m, generator=g).to(device)
+    r64 = rects.long()
+    a, b = raster.rects_to_boxes(rects), raster.rects_to_boxes(r64)
+    assert torch.equal(a.start, b.start) and torch.equal(a.end, b.end) and torch.equal(a.box_off, b.box_off)
+    assert (a.width, a.height) == (b.width, b.height)
+    v32, k32 = ck.create_alpha_brend(rects, anti, "cumprod")
+    v64, k64 = ck.create_alpha_brend(r64, anti, "cumprod")
+    assert torch.equal(k32, k64) and torch.equal(v32, v64)
+    s32, m32 = ck.grad_cumsum(rects, grad, 7)
+    s64, m64 = ck.grad_cumsum(r64, grad, 7)
+    assert torch.equal(m32, m64) and torch.equal(s32, s64)
+    odd = torch.cat([torch.zeros(1, 2, dtype=torch.int64, device=device), r64])[1:]  # a view 16 bytes into its storage
+    c = raster.rects_to_boxes(odd)
+    assert torch.equal(a.start, c.start) and torch.equal(a.box_off, c.box_off)
+    v_s, k_s = ck.create_alpha_brend(r64, anti, "cumprod", route="sort")  # the general route narrows the list first
+    assert torch.equal(k_s, k32)
+    big = r64.clone()
+    big[m // 2, 0] = 1 << 31
+    with pytest.raises(RuntimeError, match="coordinates"):
+        raster.rects_to_boxes(big)
+
+
 @pytest.mark.parametrize("flag", ["cumprod", "cumsum", "grad_cumsum"])
 def test_chunked_calls_with_carry_rows_take_the_walk(device, flag):
     """The reference's second and later chunks call `_create_alpha_brend(cat(unique_rects, rects), cat(T_min, anti),

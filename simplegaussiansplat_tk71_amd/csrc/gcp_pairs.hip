@@ -69,7 +69,8 @@ __device__ __forceinline__ int block_ranks(const unsigned (&m)[ROWS], int (&rank
 template <bool I64>
 __device__ __forceinline__ int2 rect_at(const void* __restrict__ rects, i64 i) {
   if (!I64) return reinterpret_cast<const int2*>(rects)[i];
-  const longlong2 q = reinterpret_cast<const longlong2*>(rects)[i];
+  typedef long long ll2 __attribute__((ext_vector_type(2), aligned(8)));  // a view of an int64 tensor is 8-byte aligned, no more
+  const ll2 q = reinterpret_cast<const ll2*>(rects)[i];
   const bool ok = ((unsigned long long)q.x | (unsigned long long)q.y) < 0x80000000ull;
   return ok ? make_int2((int)q.x, (int)q.y) : make_int2(-1, -1);
 }

@@ -124,7 +124,9 @@ def test_int64_rect_lists_are_read_as_they_are(device):
     s32, m32 = ck.grad_cumsum(rects, grad, 7)
     s64, m64 = ck.grad_cumsum(r64, grad, 7)
     assert torch.equal(m32, m64) and torch.equal(s32, s64)
-    odd = torch.cat([torch.zeros(1, 2, dtype=torch.int64, device=device), r64])[1:]  # a view 16 bytes into its storage
+    flat = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), r64.reshape(-1)])
+    odd = flat[1:].view(-1, 2)  # a view 8 bytes into its storage
+    assert odd.data_ptr() % 16 == 8
     c = raster.rects_to_boxes(odd)
     assert torch.equal(a.start, c.start) and torch.equal(a.box_off, c.box_off)
     v_s, k_s = ck.create_alpha_brend(r64, anti, "cumprod", route="sort")  # the general route narrows the list first

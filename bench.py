@@ -5,6 +5,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no launcher in the environment (no RANK / WORLD_SIZE) the first form starts the second one itself as
+a child process and returns its exit code (`launch_ranks`): one process per GPU either way.
+
 One "step" = one pass of the hot path over one synthetic pair list resident in HBM:
 grouped_cumprod_forward (12 B/pair) then grouped_cumprod_backward (20 B/pair) — the two
 kernels BASELINE.json's metric is quoted on.  Workload at every N: each rank
@@ -573,6 +576,44 @@ def pmc_traffic(kernel, workload):
         return None
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a fresh child — `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>`, the command
+    the module docstring gives — wait for it and return its exit code (rank 0's JSON line goes straight to the inherited
+    stdout).  This parent never touches the GPU (no torch.cuda / HIP call, and no exec from a process that did): it only
+    makes sure the HIP library is built once, so that N ranks do not compile it side by side."""
+    import signal
+    import socket
+    import subprocess
+
+    from simplegaussiansplat_tk71_amd import _build
+
+    if _build.is_stale():
+        _build.build_hip_library(force=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] no launcher in the environment: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env)
+
+    def forward(signum, _frame):  # a driver that stops this process stops the ranks too
+        if child.poll() is None:
+            child.send_signal(signum)
+
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        rc = child.wait()
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,6 +624,12 @@ def main():
                          "clip at 4096 splats per pixel: a few pixels deeper than one scan tile)")
     ap.add_argument("--cpu-sample", type=int, default=64_000_000, help="pairs in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        sys.exit(f"--gpus {args.gpus}: expected a positive rank count")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher has set up the ranks, so this process becomes the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -605,15 +652,13 @@ def main():
     from simplegaussiansplat_tk71_amd import synthetic
 
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(
-                f"--gpus {args.gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
-                f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus}"
-            )
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # one process per GPU; GCP_BENCH_BACKEND=gloo (+ ranks sharing a GPU) exists only to rehearse the N > 1 control
     # flow on a one-GPU box
     backend = os.environ.get("GCP_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > max(1, torch.cuda.device_count()):
+        sys.exit(f"--gpus {world} with RCCL needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                 "(GCP_BENCH_BACKEND=gloo lets ranks share a GPU to rehearse the control flow)")
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where the few collective operands live
@@ -756,7 +801,8 @@ def main():
 
     # Everything below is outside the timed region and optional.  With N > 1 it contains collectives; one that never
     # returns (a rank lost, a fabric problem) must not cost the run its headline: after GCP_BENCH_EXTRAS_TIMEOUT seconds
-    # (default 420) rank 0 prints the line it has and every rank leaves.
+    # (default 420) rank 0 prints the line it has and every rank leaves — with exit code 3, so that a hang shows in the
+    # run's return code and not only in a field of the line.
     watchdog = None
     if world > 1:
         import threading
@@ -768,7 +814,10 @@ def main():
                 out = headline()
                 out["sharded_frames"] = {"error": f"the optional blocks did not finish within {limit:g} s; headline only"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+                sys.stdout.flush()
+            else:
+                time.sleep(1.0)  # the launcher ends every rank as soon as one has left: rank 0 prints first
+            os._exit(3)
 
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True

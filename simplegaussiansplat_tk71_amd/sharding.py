@@ -90,6 +90,12 @@ def _padded(t: torch.Tensor, rows: int) -> torch.Tensor:
     return out
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory: device rows go through the host when the N > 1 path is rehearsed without RCCL peers
+    (ranks sharing one GPU).  With RCCL ("nccl") the rows stay in HBM and travel over xGMI."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_groups(local: torch.Tensor, shards: Sequence[Shard], dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """ONE gather of per-group rows (e.g. pixel colours [G_r, 3]) to `dst`; returns the
     concatenation [G, ...] there and None elsewhere.  Bands differ in group count, so rows are
@@ -99,10 +105,13 @@ def gather_groups(local: torch.Tensor, shards: Sequence[Shard], dst: int = 0, gr
     assert len(shards) == world and local.size(0) == shards[rank].n_groups
     rows = max(s.n_groups for s in shards)
     send = _padded(local, rows)
+    device = send.device
+    if _via_host(send, group):
+        send = send.cpu()
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, bufs, dst=dst, group=group)
-        return torch.cat([b[: s.n_groups] for b, s in zip(bufs, shards)], 0)
+        return torch.cat([b[: s.n_groups] for b, s in zip(bufs, shards)], 0).to(device)
     dist.gather(send, None, dst=dst, group=group)
     return None
 
@@ -113,14 +122,17 @@ def scatter_groups(full: Optional[torch.Tensor], shards: Sequence[Shard], like: 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     rows = max(s.n_groups for s in shards)
-    recv = like.new_empty((rows,) + tuple(like.shape[1:]))
+    host = _via_host(like, group)
+    recv = torch.empty((rows,) + tuple(like.shape[1:]), dtype=like.dtype, device="cpu" if host else like.device)
     if rank == src:
         assert full is not None and full.size(0) == shards[-1].group_end
         parts = [_padded(full[s.group_start : s.group_end], rows) for s in shards]
+        if host:
+            parts = [p.cpu() for p in parts]
         dist.scatter(recv, parts, src=src, group=group)
     else:
         dist.scatter(recv, None, src=src, group=group)
-    return recv[: shards[rank].n_groups]
+    return recv[: shards[rank].n_groups].to(like.device)
 
 
 def frame_from_groups(values: torch.Tensor, group_key: torch.Tensor, height: int, width: int) -> torch.Tensor:

@@ -280,3 +280,24 @@ def test_bench_sharded_frame_reports_a_collective_failure(monkeypatch):
         dist.destroy_process_group()
     assert out["collective_error"] is not None and "RCCL says no" in out["collective_error"]
     assert out["frame_gather_ms"] is None and out["pairs_per_s_with_gather_scatter"] is None
+
+
+@pytest.mark.timeout(300)
+def test_bench_without_a_launcher_starts_its_ranks_and_returns_their_exit_code():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment must not stop at a usage message: it starts
+    `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` as a child and returns the child's exit
+    code.  On a box with fewer than two GPUs the ranks refuse (RCCL needs a GPU per rank) — which is what proves here
+    that they were started and that their failure reaches the caller's return code."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                           "GCP_BENCH_BACKEND")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert "starting 2 ranks" in res.stderr and "torch.distributed.run" in res.stderr
+    if torch.cuda.device_count() < 2:
+        assert res.returncode != 0
+        assert "needs 2 GPUs" in res.stderr
+        assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -58,7 +58,7 @@ extern "C" {
 #define GCP_ERR_WORKSPACE 2        /* workspace too small / misaligned */
 #define GCP_ERR_HIP 3              /* a HIP call failed: see gcp_last_hip_error() */
 
-#define GCP_ABI_VERSION 3
+#define GCP_ABI_VERSION 4
 
 /* ABI version of the loaded library (== GCP_ABI_VERSION it was built with). */
 int gcp_abi_version(void);
@@ -169,6 +169,24 @@ int gcp_cumsum_reverse_carry(const float* x, const int32_t* inv, const float* ca
  */
 int gcp_check_groups(const int32_t* inv, const int32_t* inv_len, int64_t n,
                      int64_t n_groups, int64_t* n_bad, void* stream);
+
+/*
+ * Operand checks for the two forms that index memory through an operand (debug aids like gcp_check_groups: they
+ * allocate a scratch buffer and synchronise `stream`).  The scans themselves trust these operands — an `index` entry
+ * outside [0, n) or an `inv` entry outside [0, n_groups) is an out-of-bounds device access.
+ *   gcp_check_permutation: GCP_OK if index[0..n) is a permutation of 0..n-1 (what the indexed scans need: they read
+ *     x[index[i]] and write y[index[i]]), GCP_ERR_INVALID_ARGUMENT otherwise; *n_bad (may be NULL) receives the
+ *     number of entries that are out of range or repeat an earlier value.
+ *   gcp_check_group_ids: GCP_OK if every inv[i] lies in [0, n_groups) (what the carry forms index `carry` with),
+ *     GCP_ERR_INVALID_ARGUMENT otherwise; *n_bad (may be NULL) = entries out of range.
+ *   gcp_set_validate_operands(1) (or environment GCP_VALIDATE_OPERANDS=1), process-wide, default off: every
+ *     gcp_cum*_indexed call first runs gcp_check_permutation on its `index`, every gcp_cum*_carry call
+ *     gcp_check_group_ids on its `inv`, and returns GCP_ERR_INVALID_ARGUMENT WITHOUT launching the scan when the
+ *     operand is bad — at the price of one extra pass and a host synchronisation per call (not graph-capturable).
+ */
+int gcp_check_permutation(const int32_t* index, int64_t n, int64_t* n_bad, void* stream);
+int gcp_check_group_ids(const int32_t* inv, int64_t n, int64_t n_groups, int64_t* n_bad, void* stream);
+int gcp_set_validate_operands(int on);
 
 /* Tuning / introspection (used by bench.py and the tests). */
 /* Elements per scan tile of the loaded build. */
@@ -293,7 +311,8 @@ int gcp_rects_key_range(const int32_t* rects_xy, int64_t n, int32_t* out_dev, vo
  *   in depth order; mode 2: sum from this one to the deepest (grad_cumsum's flipped scan, gs_model.py:716-722).
  * Every pixel is scanned sequentially in depth order (the association of the CPU statement).  8 B / pair.  Feed the result
  * to gcp_compact_finish.  n_pairs = M = box_off[n_gauss], the length of x and inclusive (< 2^31; up to 2^30 the kernel
- * addresses pairs by 32-bit byte offsets).  dropped_per_tile: NULL, or int32[ceil(n_pairs / 4096)] that receives, for
+ * addresses pairs by 32-bit byte offsets).  width + 1 must stay below 2^22 (2^24 beyond 2^30 pairs): a pair's position is
+ * formed with one 24-bit multiply by the box width; GCP_ERR_INVALID_ARGUMENT otherwise.  dropped_per_tile: NULL, or int32[ceil(n_pairs / 4096)] that receives, for
  * every 4096 consecutive pairs, how many inclusive values are exactly 0 (integer adds, one per wave and list entry that
  * has any: deterministic) — the per-tile counts gcp_compact_finish would otherwise read the array once more for. */
 int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
@@ -306,8 +325,9 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
  * of boxes yields about as many rectangles as elements, and the caller then sorts instead.
  *   gcp_rects_rows: rows = maximal runs (x, y), (x+1, y), ...  row_start[k] = index of the k-th row's first element,
  *     row_start[rows] = n, row_xy[k] = its (x, y); both have room for row_capacity entries.  info (device int32[5]) =
- *     {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: the list has more than row_capacity - 1 rows (or a
- *     coordinate does not fit x < 2^14, y < 2^17) — nothing was written, sort instead.  gcp_rects_rows_capacity(n) = n / 2 + 2
+ *     {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: the list has more than row_capacity - 1 rows, or an
+ *     x >= 10000 (the reference's key y * 10000 + x then merges different pixels, gs_model.py:538-541: only the key-based
+ *     sort route reproduces its groups) or a y >= 2^17 — nothing was written, sort instead.  gcp_rects_rows_capacity(n) = n / 2 + 2
  *     is what a list of boxes is allowed; a caller whose list starts or ends with c single-pixel carry rows (the
  *     `cutting_number` rows of gs_model.py:611, :636 — lexicographically sorted unique pixels: they come out as one-pixel-wide
  *     rectangles) passes c + gcp_rects_rows_capacity(n - c).

@@ -37,6 +37,9 @@ SIGNATURES = {
         [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _i64, _c_void_p, _sz, _c_void_p],
     ),
     "gcp_check_groups": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, ctypes.POINTER(_i64), _c_void_p]),
+    "gcp_check_permutation": (ctypes.c_int, [_c_void_p, _i64, ctypes.POINTER(_i64), _c_void_p]),
+    "gcp_check_group_ids": (ctypes.c_int, [_c_void_p, _i64, _i64, ctypes.POINTER(_i64), _c_void_p]),
+    "gcp_set_validate_operands": (ctypes.c_int, [ctypes.c_int]),
     "gcp_tile_elems": (ctypes.c_int, []),
     "gcp_last_fallback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
     "gcp_last_lookback_tiles": (ctypes.c_int, [_c_void_p, _c_void_p, ctypes.POINTER(_i64)]),
@@ -98,7 +101,7 @@ SIGNATURES = {
     "gcp_project_backward": (ctypes.c_int, [_c_void_p] * 7 + [_i64, _i32, _i32] + [_c_void_p] * 10),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

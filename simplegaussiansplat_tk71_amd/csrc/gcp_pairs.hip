@@ -164,7 +164,10 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
     // kernel's 1.4 ms when first written that way); the range settles after the first few blocks and the rest only read.
     const int bx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])), by = max(max(s_my[0], s_my[1]), max(s_my[2], s_my[3]));
     const int bn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
-    if (bx >= (1 << 14) || by >= (1 << 17)) info[4] = 1;  // does not fit the packed slot record
+    // x >= 10000: the reference's pixel key y * 10000 + x (gs_model.py:538-541) then runs DIFFERENT pixels together —
+    // (10000, 0) and (0, 1) share key 10000 — and only the key-based sort route reproduces its groups; the walk groups by
+    // pixel.  y >= 2^17: does not fit the packed slot record (nor the reference's int32 key).
+    if (bx >= 10000 || by >= (1 << 17)) info[4] = 1;
     if (bx > __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(info + 1, bx);
     if (by > __hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(info + 2, by);
     if (bn < __hip_atomic_load(info + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(info + 3, bn);

@@ -1743,6 +1743,9 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
   // pair positions as 32-bit byte offsets while the list is no longer than 2^30 pairs (GCP_WALK_WIDE=1 forces the other form)
   const char* fw = getenv("GCP_WALK_WIDE");  // read per call: the tests switch it inside one process
   const bool wide = (fw && *fw && atoi(fw) != 0) || n_pairs > (1LL << 30);
+  // a pair's position is formed with ONE 24-bit multiply (row in the tile) x (box width, in bytes unless WIDE): a box can be
+  // as wide as the image, so the image has to fit — 2^22 columns in the byte-offset form, 2^24 in the element form
+  if ((int64_t)width + 1 >= (wide ? (1LL << 24) : (1LL << 22))) return GCP_ERR_INVALID_ARGUMENT;
   const bool count = dropped_per_tile != nullptr;
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);

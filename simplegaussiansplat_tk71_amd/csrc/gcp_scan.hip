@@ -943,6 +943,31 @@ __global__ void gcp_check_groups_kernel(const int* inv, const int* inv_len, i64 
   if (local) atomicAdd(bad, local);
 }
 
+// gcp_check_permutation: every index[i] in [0, n) and none twice (one bit per value; the atomic OR returns whether the
+// bit was already set).  Integer counts only: the result does not depend on the order.
+__global__ void gcp_check_perm_kernel(const int* index, i64 n, unsigned* seen, unsigned long long* bad) {
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int v = index[i];
+    if (v < 0 || (i64)v >= n) { ++local; continue; }
+    const unsigned bit = 1u << (v & 31);
+    if (atomicOr(seen + (v >> 5), bit) & bit) ++local;
+  }
+  if (local) atomicAdd(bad, local);
+}
+
+// gcp_check_group_ids: every inv[i] in [0, G) — what the carry forms index `carry` with
+__global__ void gcp_check_ids_kernel(const int* inv, i64 n, i64 G, unsigned long long* bad) {
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int g = inv[i];
+    if (g < 0 || (i64)g >= G) ++local;
+  }
+  if (local) atomicAdd(bad, local);
+}
+
 // ----------------------------------------------------------------------------
 // Host side
 // ----------------------------------------------------------------------------
@@ -989,7 +1014,83 @@ int get_internal_ws(size_t need, hipStream_t stream, void** out) {
   return GCP_OK;
 }
 
+// compute units of the current device (0 if the query fails: the caller then keeps its own bound)
+int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) return 0;
+    cached[dev].store(cu, std::memory_order_relaxed);
+    v = cu;
+  }
+  return v;
+}
+
 std::atomic<long long> g_patience_us{-2};  // -2: not set yet (environment GCP_DESC_WAIT_US, else the default)
+std::atomic<int> g_validate{-1};           // -1: not set yet (environment GCP_VALIDATE_OPERANDS, else off)
+
+bool validate_operands() {
+  int v = g_validate.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* s = getenv("GCP_VALIDATE_OPERANDS");
+    v = (s && *s && atoi(s) != 0) ? 1 : 0;
+    g_validate.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
+// Count, on `stream`, what one of the two checking kernels finds; synchronises.  seen_words > 0: a zeroed bitmap of that
+// many words is handed to the kernel (the permutation check).
+template <typename Launch>
+int count_bad(hipStream_t stream, size_t seen_words, unsigned long long* h_out, Launch launch) {
+  char* d = nullptr;
+  const size_t bytes = 8 + seen_words * 4;
+  GCP_HIP(hipMalloc((void**)&d, bytes));
+  hipError_t e = hipMemsetAsync(d, 0, bytes, stream);
+  if (e == hipSuccess) {
+    launch((unsigned long long*)d, (unsigned*)(d + 8));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_out, d, sizeof(*h_out), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d);
+  return e == hipSuccess ? GCP_OK : hip_fail(e);
+}
+
+int check_permutation_impl(const int* index, i64 n, int64_t* n_bad, hipStream_t stream) {
+  if (n_bad) *n_bad = 0;
+  if (n < 0 || n > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GCP_OK;
+  if (!index) return GCP_ERR_INVALID_ARGUMENT;
+  unsigned long long h = 0;
+  i64 blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int st = count_bad(stream, (size_t)((n + 31) / 32), &h, [&](unsigned long long* bad, unsigned* seen) {
+    hipLaunchKernelGGL(gcp_check_perm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, index, n, seen, bad);
+  });
+  if (st != GCP_OK) return st;
+  if (n_bad) *n_bad = (int64_t)h;
+  return h ? GCP_ERR_INVALID_ARGUMENT : GCP_OK;
+}
+
+int check_group_ids_impl(const int* inv, i64 n, i64 n_groups, int64_t* n_bad, hipStream_t stream) {
+  if (n_bad) *n_bad = 0;
+  if (n < 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GCP_OK;
+  if (!inv || n_groups <= 0) return GCP_ERR_INVALID_ARGUMENT;
+  unsigned long long h = 0;
+  i64 blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int st = count_bad(stream, 0, &h, [&](unsigned long long* bad, unsigned*) {
+    hipLaunchKernelGGL(gcp_check_ids_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, inv, n, n_groups, bad);
+  });
+  if (st != GCP_OK) return st;
+  if (n_bad) *n_bad = (int64_t)h;
+  return h ? GCP_ERR_INVALID_ARGUMENT : GCP_OK;
+}
 
 int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
@@ -1071,7 +1172,12 @@ int launch_scan(const float* in0, const float* in1, const float* in2, const int*
     // the follow-up kernel: a no-op walk over the tile descriptors unless a tile gave up waiting.  Every block ends
     // with one atomic on the same word (the last one advances the launch counter): 256 of them cost 7 us, so the
     // grid is small unless the descriptor walk is switched off and the kernel has real work on every long group
-    const i64 want = a.patience < 0 ? kFixBlocks : kFixBlocksQuiet;
+    // Its rare path spins in a hand-written grid barrier, so every block of the grid must be resident together: never
+    // more blocks than the device has CUs (one 256-thread block of this kernel always fits a CU: 256 on a whole MI355X,
+    // 32 on a CPX partition), queried once per device.
+    i64 want = a.patience < 0 ? kFixBlocks : kFixBlocksQuiet;
+    const int cus = device_cu_count();
+    if (cus > 0 && want > cus) want = cus;
     const unsigned fb = (unsigned)(ntiles < want ? ntiles : want);
     if (index) hipLaunchKernelGGL((gcp_fallback<MODE, false, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
     else if (carry) hipLaunchKernelGGL((gcp_fallback<MODE, !Mode<MODE>::kBwd>), dim3(fb), dim3(kThreads), 0, stream, a);
@@ -1133,36 +1239,60 @@ int gcp_cumsum_reverse(const float* x, const int32_t* key, float* y, int64_t n, 
 int gcp_cumprod_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
                                 void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_permutation_impl(index, n, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMPROD_FWD>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
 }
 
 int gcp_cumsum_forward_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
                                void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_permutation_impl(index, n, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMSUM_FWD>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
 }
 
 int gcp_cumsum_reverse_indexed(const float* x, const int32_t* sorted_key, const int32_t* index, float* y, int64_t n,
                                void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && !index) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_permutation_impl(index, n, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, sorted_key, y, n, ws, ws_bytes, stream, nullptr, index);
 }
 
 int gcp_cumprod_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
                               int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_group_ids_impl(inv, n, n_groups, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMPROD_FWD>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
 }
 
 int gcp_cumsum_forward_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
                              int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_group_ids_impl(inv, n, n_groups, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMSUM_FWD>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
 }
 
 int gcp_cumsum_reverse_carry(const float* x, const int32_t* inv, const float* carry, float* y, int64_t n,
                              int64_t n_groups, void* ws, size_t ws_bytes, void* stream) {
   if (n > 0 && (!carry || n_groups <= 0)) return GCP_ERR_INVALID_ARGUMENT;
+  if (validate_operands()) {
+    const int st = check_group_ids_impl(inv, n, n_groups, nullptr, (hipStream_t)stream);
+    if (st != GCP_OK) return st;
+  }
   return launch_scan<M_CUMSUM_REV>(x, nullptr, nullptr, inv, y, n, ws, ws_bytes, stream, carry);
 }
 
@@ -1197,6 +1327,19 @@ int gcp_check_groups(const int32_t* inv, const int32_t* inv_len, int64_t n, int6
   (void)hipFree(d);
   if (e != hipSuccess) return hip_fail(e);
   *n_bad = (int64_t)h;
+  return GCP_OK;
+}
+
+int gcp_check_permutation(const int32_t* index, int64_t n, int64_t* n_bad, void* stream) {
+  return check_permutation_impl(index, (i64)n, n_bad, (hipStream_t)stream);
+}
+
+int gcp_check_group_ids(const int32_t* inv, int64_t n, int64_t n_groups, int64_t* n_bad, void* stream) {
+  return check_group_ids_impl(inv, (i64)n, (i64)n_groups, n_bad, (hipStream_t)stream);
+}
+
+int gcp_set_validate_operands(int on) {
+  g_validate.store(on ? 1 : 0, std::memory_order_relaxed);
   return GCP_OK;
 }
 

@@ -350,7 +350,16 @@ def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, im
         return _scan_boxes_compact(startpoint, endpoint, anti_opacity, image_width, image_height, flag)
 
 
-def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=None, route="auto"):
+def _mask_in_order(out, mask_order):
+    """[values, mask] with the mask in the caller's order: "original" (row i of the mask is row i of the inputs) or
+    "reference" — what gs_model.py:716-722 returns: the mask of the FLIPPED arrays, never flipped back (:721-722), row i
+    of it being row n - 1 - i of the kept input range; `_backward_batch` applies it as it is (:642-645)."""
+    if mask_order == "reference":
+        return [out[0], out[1].flip(0)]
+    return out
+
+
+def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=None, route="auto", mask_order="original"):
     """Per-pixel exclusive SUFFIX sum of `grad` in original pair order.
 
     reference: gs_model.py:716-722 (flip, _create_alpha_brend(flag="cumsum"), flip).
@@ -358,27 +367,32 @@ def grad_cumsum(rects, grad, cutting_number=None, *, key_bits=None, image_size=N
     un-flipped list, so this walks the tile lists back to front (route "boxes") or runs one
     indexed reverse scan (route "sort"); routes as for `create_alpha_brend`.  `cutting_number` counts
     rows at the START of the flipped arrays, i.e. the LAST rows of the inputs
-    (gs_model.py:636 appends the carry rows at the end before the flip).  The mask is
-    returned in ORIGINAL order (the reference leaves it flipped).
+    (gs_model.py:636 appends the carry rows at the end before the flip).
+    mask_order="original" (default): the mask is returned in the order of the inputs; mask_order="reference": in the
+    reference's order — flipped, as gs_model.py:721-722 leaves it — bit for bit what the reference returns.
     """
     if route not in ("auto", "boxes", "sort"):
         raise ValueError(route)
+    if mask_order not in ("original", "reference"):
+        raise ValueError(mask_order)
     with torch.no_grad():
         if route != "sort":
             out = _rects_as_boxes(rects, grad, "cumsum_reverse", cutting_number)
             if out is not None:
-                return out
+                return _mask_in_order(out, mask_order)
             if route == "boxes":
                 raise RuntimeError("grad_cumsum: rects do not come apart into boxes (route='boxes')")
         sorted_inv, index = _raster.sort_rects(rects.rects if isinstance(rects, PreparedRects) else rects, key_bits, image_size)
-        return _scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number)
+        return _mask_in_order(_scan_unsort_compact(sorted_inv, index, grad, "cumsum_reverse", cutting_number), mask_order)
 
 
-def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height):
+def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height, *, mask_order="original"):
     """`grad_cumsum` (gs_model.py:716-722) from the boxes: the tile lists walked back to front; same [values, mask] as
     `grad_cumsum(rects, grad)` (values within fp32 round-off, masks as explained at `create_alpha_brend_boxes`)."""
+    if mask_order not in ("original", "reference"):
+        raise ValueError(mask_order)
     with torch.no_grad():
-        return _scan_boxes_compact(startpoint, endpoint, grad, image_width, image_height, "cumsum_reverse")
+        return _mask_in_order(_scan_boxes_compact(startpoint, endpoint, grad, image_width, image_height, "cumsum_reverse"), mask_order)
 
 
 class custom_autograd_grouped_cumprod(torch.autograd.Function):

@@ -34,6 +34,9 @@ __all__ = [
     "grouped_cumsum_reverse_carry",
     "Workspace",
     "check_groups",
+    "check_permutation",
+    "check_group_ids",
+    "set_validate_operands",
     "last_fallback_tiles",
     "last_lookback_tiles",
     "set_lookback_wait_us",
@@ -194,8 +197,8 @@ def _forward_indexed(fn_name, x, sorted_key, index, y):
 def grouped_cumprod_forward_indexed(x, sorted_key, index, out):
     """out[index[i]] = running product, inside runs of equal adjacent sorted_key, of x[index[i]]: gather, grouped scan and
     un-sort of `_create_alpha_brend` (gs_model.py:548-555) in one pass; `x` / `out` in the original pair order,
-    `sorted_key` / `index` from the stable sort of the pixel keys.  `index` must be a permutation (not checked).  Not in
-    the reference module."""
+    `sorted_key` / `index` from the stable sort of the pixel keys.  `index` must be a permutation: not checked unless
+    `set_validate_operands(True)` (see `check_permutation`).  Not in the reference module."""
     _forward_indexed("gcp_cumprod_forward_indexed", x, sorted_key, index, out)
 
 
@@ -284,6 +287,43 @@ def check_groups(inv, inv_len):
         status = lib.gcp_check_groups(inv.data_ptr(), inv_len.data_ptr(), n, inv_len.numel(), ctypes.byref(bad), stream)
     _lib.check(status, "gcp_check_groups")
     return bad.value
+
+
+def check_permutation(index):
+    """Number of entries of `index` (int32[n]) that are outside [0, n) or repeat an earlier value: 0 iff it is a
+    permutation — what the indexed scans read and write through, unchecked (debug aid, synchronises)."""
+    dev = index.device
+    _check_tensor(index, "index", torch.int32, dev)
+    bad = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        status = _lib.load().gcp_check_permutation(index.data_ptr(), index.numel(), ctypes.byref(bad),
+                                                   torch.cuda.current_stream(dev).cuda_stream)
+    if status not in (0, 1):
+        _lib.check(status, "gcp_check_permutation")
+    return bad.value
+
+
+def check_group_ids(inv, n_groups):
+    """Number of entries of `inv` (int32[n]) outside [0, n_groups): the carry forms index `carry` with them, unchecked
+    (debug aid, synchronises)."""
+    dev = inv.device
+    _check_tensor(inv, "inv", torch.int32, dev)
+    _require(int(n_groups) > 0 or inv.numel() == 0, "n_groups: must be positive for a non-empty input")
+    bad = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        status = _lib.load().gcp_check_group_ids(inv.data_ptr(), inv.numel(), int(n_groups), ctypes.byref(bad),
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+    if status not in (0, 1):
+        _lib.check(status, "gcp_check_group_ids")
+    return bad.value
+
+
+def set_validate_operands(on):
+    """Process-wide, default off (environment GCP_VALIDATE_OPERANDS=1 turns it on): the indexed scans check that `index`
+    is a permutation and the carry forms that `inv` lies in [0, len(carry)) BEFORE they launch, and raise RuntimeError
+    ("invalid argument") instead of reading or writing out of bounds — one extra pass and a host synchronisation per
+    call."""
+    _lib.check(_lib.load().gcp_set_validate_operands(1 if on else 0), "gcp_set_validate_operands")
 
 
 def _last_stat(fn_name, device):

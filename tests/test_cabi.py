@@ -19,7 +19,7 @@ def test_library_builds_and_loads():
     path = _build.build_hip_library()
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.gcp_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.gcp_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 def _parity_on_device(got, want, scale, what, tol=TOL):
     """tests/util.assert_parity evaluated on the GPU (8.3e8-element arrays in fp64 on the host would dominate the run
-    time): |got - want| <= tol * (1 + |scale|) element by element."""
+    time): |got - want| <= tol * (1 + |scale|) element by element; scale=None (transmittance): |got - want| <= tol absolute."""
     dev = got.device
     n = got.numel()
     step = 1 << 27
@@ -32,7 +32,7 @@ def _parity_on_device(got, want, scale, what, tol=TOL):
         hi = min(n, lo + step)
         g = got[lo:hi].double()
         w = want[lo:hi].to(dev).double()
-        s = scale[lo:hi].to(dev).double().abs()
+        s = torch.zeros_like(w) if scale is None else scale[lo:hi].to(dev).double().abs()
         err = (g - w).abs()
         bad = err > tol * (1.0 + s)
         if bool(bad.any()):
@@ -75,7 +75,7 @@ def test_scans_full_size_vs_oracle(device, name):
     # a1 grouped_cumprod_forward (reference: grouped_cumprod_forward.cu:6-24)
     gc.grouped_cumprod_forward(p.x, p.key, out)
     want_y = co.cumprod_forward(xc, kc)
-    report["a1"] = _parity_on_device(out, want_y, want_y, f"{name} a1 cumprod forward")
+    report["a1"] = _parity_on_device(out, want_y, None, f"{name} a1 cumprod forward")  # absolute 1e-5
     y = out.clone()
 
     # a2 grouped_cumsum_forward on signed values (grouped_cumsum_forward.cu:6-24)
@@ -97,7 +97,7 @@ def test_scans_full_size_vs_oracle(device, name):
         # the literal O(sum L^2) fp32 loops of the reference kernel are affordable at mean depth 8
         lit = co.cumprod_backward_mt(xc, yc, goc, ic, p.inv_len.cpu(), min(16, co.max_threads()))
         _parity_on_device(out, lit, scale_g, f"{name} a3 vs the literal fp32 loops")
-    print(f"{name}: {m} pairs, {p.n_groups} groups, worst err/(1+scale): " + ", ".join(f"{k} {v:.2e}" for k, v in report.items()))
+    print(f"{name}: {m} pairs, {p.n_groups} groups, worst err/(1+scale) (a1: absolute): " + ", ".join(f"{k} {v:.2e}" for k, v in report.items()))
 
 
 def _scene_from_config(name, device, seed=0):

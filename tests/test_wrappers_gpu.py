@@ -51,8 +51,8 @@ def test_create_alpha_brend_and_grad_cumsum_cfg2_scene_vs_oracle(device, how):
         assert torch.equal(sk.cpu(), w_sorted.to(torch.int32)) and torch.equal(idx.cpu().long(), w_index)
         assert torch.equal(mask.cpu(), w_mask), flag
         assert vals.numel() == int(w_mask.sum())
-        # values in [0, 1] (products) or sums of a few dozen values in [0, 1]: |err| <= 1e-5 * (1 + |want|)
-        _parity(vals, w_vals, w_vals.abs(), flag)
+        # transmittance: 1e-5 ABSOLUTE; prefix sums of a few dozen values in [0, 1]: |err| <= 1e-5 * (1 + |want|)
+        _parity(vals, w_vals, torch.zeros_like(w_vals) if flag == "cumprod" else w_vals.abs(), flag)
         # the same from the boxes (tile-list walk, no M-sized sort): every pixel scanned in the CPU statement's own order
         b_vals, b_mask = ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, sc["width"], sc["height"], flag)
         assert torch.equal(b_mask.cpu(), w_mask), flag
@@ -93,11 +93,14 @@ def test_wrappers_small_scenes_and_cutting_number(device, n_gauss, w, h, mh, see
             vals, mask = ck.create_alpha_brend(rects, anti.to(device), flag, cut, route=route)
             w_vals, w_mask, _, _ = ow.create_alpha_brend(rects.cpu(), anti, flag, cut)
             assert torch.equal(mask.cpu(), w_mask), (route, flag)
-            torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4 if flag == "cumsum" else TOL, rtol=TOL)
+            # transmittance: 1e-5 absolute; sums: relative to their size
+            torch.testing.assert_close(vals.cpu(), w_vals, **(dict(atol=1e-4, rtol=TOL) if flag == "cumsum" else dict(atol=TOL, rtol=0)))
         vals, mask = ck.grad_cumsum(rects, grad.to(device), cut, route=route)
         w_vals, w_mask_flipped = ow.grad_cumsum(rects.cpu(), grad, cut)
         assert torch.equal(mask.cpu(), w_mask_flipped.flip(0)), route
         torch.testing.assert_close(vals.cpu(), w_vals, atol=1e-4, rtol=TOL)
+        # the reference's own mask order (flipped, gs_model.py:721-722), as is
+        assert torch.equal(ck.grad_cumsum(rects, grad.to(device), cut, route=route, mask_order="reference")[1].cpu(), w_mask_flipped), route
 
 
 def test_int64_rect_lists_are_read_as_they_are(device):
@@ -674,4 +677,59 @@ def test_wrapper_and_function_kernels_read_nothing_past_the_end_of_their_inputs(
         outs.append((img.detach(), vinv.grad, op.grad, l_d.grad))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    torch.cuda.synchronize()
+
+
+def test_lists_with_x_beyond_the_key_stride_take_the_key_based_route(device):
+    """The reference groups pairs by the KEY y * 10000 + x (gs_model.py:538-541): with x >= 10000 different pixels share a
+    key — (10003, 0) and (3, 1) — and belong to ONE group.  The walk groups by pixel, so such a list must not take it:
+    route="auto" gives what route="sort" and the CPU statement give; route="boxes" refuses."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import raster
+
+    # two boxes whose pixels collide through the key: columns 9990..10013 of rows 0..5, and columns 0..20 of rows 0..6
+    start = torch.tensor([[9990, 0], [0, 0]], dtype=torch.int32, device=device)
+    end = torch.tensor([[10013, 5], [20, 6]], dtype=torch.int32, device=device)
+    rects = raster.expand_rects(start, end, 16000, 100)
+    m = rects.size(0)
+    assert int(rects[:, 0].max()) >= 10000
+    keys = (rects[:, 1].long() * 10000 + rects[:, 0].long()).cpu()
+    assert keys.unique().numel() < m  # some pairs of DIFFERENT pixels share a key
+    g = torch.Generator().manual_seed(5)
+    anti = (1.0 - 0.9 * torch.rand(m, generator=g))
+    grad = torch.randn(m, generator=g)
+    assert raster.rects_to_boxes(rects) is None
+    for flag in ("cumprod", "cumsum"):
+        w_vals, w_mask, _, _ = ow.create_alpha_brend(rects.cpu(), anti, flag)
+        for route in ("auto", "sort"):
+            vals, mask = ck.create_alpha_brend(rects, anti.to(device), flag, route=route)
+            assert torch.equal(mask.cpu(), w_mask), (flag, route)
+            torch.testing.assert_close(vals.cpu(), w_vals, atol=TOL, rtol=TOL)
+    w_vals, w_mask_flipped = ow.grad_cumsum(rects.cpu(), grad)
+    for route in ("auto", "sort"):
+        vals, mask = ck.grad_cumsum(rects, grad.to(device), route=route)
+        assert torch.equal(mask.cpu(), w_mask_flipped.flip(0)), route
+        torch.testing.assert_close(vals.cpu(), w_vals, atol=2e-5, rtol=TOL)
+    with pytest.raises(RuntimeError, match="boxes"):
+        ck.create_alpha_brend(rects, anti.to(device), "cumprod", route="boxes")
+
+
+def test_walk_refuses_images_too_wide_for_its_24_bit_multiply(device):
+    """A pair's position is one 24-bit multiply of (row in the tile) x (box width in bytes): an image of 2^22 columns or
+    more is refused (GCP_ERR_INVALID_ARGUMENT) instead of being walked with truncated offsets."""
+    from simplegaussiansplat_tk71_amd import _lib
+
+    lib = _lib.load()
+    t = torch.zeros(16, dtype=torch.int32, device=device)
+    f = torch.zeros(16, device=device)
+    f2 = torch.zeros(16, device=device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    for width, want in (((1 << 22) - 2, 0), ((1 << 22) - 1, 1), (1 << 23, 1)):
+        # one Gaussian with an empty tile list: nothing is read through the dummy pointers
+        tile_start = torch.zeros((width >> 4) + 2, dtype=torch.int32, device=device)  # (width / 16 + 1) x 1 tiles, all empty
+        rc = lib.gcp_pairs_scan_boxes(t.data_ptr(), t.data_ptr(), 1, width, 15, tile_start.data_ptr(), t.data_ptr(), t.data_ptr(),
+                                      f.data_ptr(), f2.data_ptr(), 16, 0, None, st)
+        torch.cuda.synchronize()
+        assert rc == want, (width, rc)
     torch.cuda.synchronize()

@@ -57,12 +57,15 @@ def make_values(n, seed, kind="alpha"):
 
 
 def assert_parity(got, want32, scale, what="", tol=TOL):
-    """|got - want32| <= tol * (1 + scale) elementwise.  `scale` is the magnitude of the
-    quantity with every term taken in absolute value (fp64), i.e. the usual condition
-    scale of a sum; for products it is the value itself."""
+    """The tolerance rule of the parity tests.
+
+    scale=None — transmittance, colour and every other product of factors in [0, 1] (row a1, the T of a5, the image):
+      |got - want32| <= tol ABSOLUTE, BASELINE.json north_star's "within 1e-5 fp32 on transmittance and colour" to the letter.
+    scale given — sums and gradients, which are not bounded by 1: |got - want32| <= tol * (1 + scale) elementwise, `scale`
+      being the magnitude of the quantity with every term taken in absolute value (fp64): the condition scale of the sum."""
     got = got.detach().cpu().double()
     want = want32.detach().cpu().double()
-    scale = scale.detach().cpu().double().abs()
+    scale = torch.zeros_like(want) if scale is None else scale.detach().cpu().double().abs()
     err = (got - want).abs()
     bound = tol * (1.0 + scale)
     bad = err > bound

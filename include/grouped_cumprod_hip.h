@@ -319,6 +319,35 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
                          const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
                          float* inclusive, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream);
 
+/* The walk writing the FINAL values of _create_alpha_brend (gs_model.py:557-564), so that a list that drops nothing needs no
+ * compaction pass at all.  Same walk as gcp_pairs_scan_boxes, same arguments, but every pair receives
+ *   values[pair] = inclusive / x[pair] (mode 0, gs_model.py:562)  or  inclusive - x[pair] (modes 1, 2, :564)
+ * — the fp32 operation gcp_compact_finish would apply to the stored inclusive value: the same bits — and
+ *   keep[pair]   = (inclusive != 0)                                  (gs_model.py:560, :575-578)
+ * as one byte per pair (the call sets every byte to 1 and the walk clears the bytes of the pairs it drops);
+ * dropped_per_tile (required, int32[ceil(n_pairs / 4096)]) counts them per 4096 consecutive pairs.  When
+ * gcp_compact_kept_count reports that everything was kept, `values` and `keep` ARE the result of _create_alpha_brend
+ * (8 B per pair + the 1 B fill of the mask instead of 21); otherwise gcp_compact_kept_write moves the kept values together
+ * (5 B read + 4 B written per pair). */
+int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                           const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
+                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream);
+
+/* The stream compaction that remains after gcp_pairs_finish_boxes, split at the one device->host read that sizes the result
+ * (the reference's `output[mask]`, gs_model.py:575-578, synchronises likewise):
+ *   gcp_compact_kept_count: count_dev[0] (device int32) = number of set bytes of keep[begin, end) — the rows a
+ *     `cutting_number` slice leaves (gs_model.py:557-559) — and, in ws, the rank of every 4096-element tile of the range.
+ *     dropped_per_tile (may be NULL; what the walk counted for the WHOLE array of n_total elements) is used instead of
+ *     reading the keep bytes when the range starts at a multiple of 4096 and ends at one or at n_total.
+ *   gcp_compact_kept_write: values_out[k] = values_in[i] for the k-th kept i of [begin, end), in order; `ws` as the count
+ *     call left it, for the same range.  Not needed when the count equals end - begin.
+ * Stable, no atomics, deterministic.  ws: gcp_compact_kept_workspace_bytes(end - begin). */
+size_t gcp_compact_kept_workspace_bytes(int64_t n);
+int gcp_compact_kept_count(const uint8_t* keep, const int32_t* dropped_per_tile, int64_t n_total, int64_t begin, int64_t end,
+                           int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
+int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, const void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* The rect list of the reference cut back into rectangles (gcp_pairs.hip), so that _create_alpha_brend / grad_cumsum can
  * take the tile-walk route (gcp_pairs_scan_boxes) from nothing but `rects` — which `_create_rects` always writes as a
  * concatenation of row-major boxes (gs_model.py:480-482, uitility.py:336-366).  Valid for ANY list: a list that is not made
@@ -338,6 +367,27 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
  *     index of the rectangle's first pair, box_off[n_rects] = n): the arguments of gcp_bin_tiles* and gcp_pairs_scan_boxes.
  * Each cut is a stable stream compaction without atomics on the data path (per-tile counts, one exclusive scan, ranked
  * writes); the first reads the M-sized list once.  ws: the matching *_workspace_bytes. */
+/* The three cuts AND the binning's counting pass in ONE call with nothing read back in between (gcp_rects_cut): what
+ * _create_alpha_brend / grad_cumsum run by default.  Every stage takes its predecessor's count from device memory; the caller
+ * reads info8 once:
+ *   info8 (device int32[8]) = {rows, max x, max y, min coordinate, flags, rectangles, K, 0}
+ *   flags: 0 = start_xy / end_xy / box_off (as gcp_rectangle_boxes) and tile_off (as gcp_bin_tiles_count: exclusive prefix
+ *     sums of the tiles every rectangle touches, tile_off[rectangles] = K — the image being [0, max x] x [0, max y], the
+ *     binning's clamp is the identity) are valid: hand them to gcp_bin_tiles_fill(…, max x, max y, tile_off, K, …).
+ *     1 = a coordinate the walk cannot take (x >= 10000, y >= 2^17: see gcp_rects_rows) — sort instead;
+ *     2 = a 4096-pair tile holds more than slot_rows rows — repeat with more slots (gcp_rects_rows: 4096) or sort;
+ *     4 = more than rect_capacity rectangles; 8 = K does not fit int32.  A negative min coordinate: refuse the list.
+ *   slot_rows: row records a tile of boxes may park (<= 4096; 512 serves boxes of 8 columns and more).  carry_front /
+ *     carry_back: the list starts / ends with that many single-pixel carry rows (the `cutting_number` rows of gs_model.py:611,
+ *     :636): their tiles get one slot per element.  rect_capacity: rectangles start_xy / end_xy (int32[cap][2]), box_off and
+ *     tile_off (int32[cap + 1]) have room for.
+ * Scratch (ws, 256-byte aligned): 8 B x slot_rows per tile + 12 B per row slot + a few words per tile: 2.5 B per pair at
+ * slot_rows = 512, against gcp_rects_rows' 8 B + the caller's 6 B per pair. */
+size_t gcp_rects_cut_workspace_bytes(int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows, int64_t rect_capacity);
+int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows,
+                  int64_t rect_capacity, int32_t* start_xy, int32_t* end_xy, int32_t* box_off, int32_t* tile_off, int32_t* info8,
+                  void* ws, size_t ws_bytes, void* stream);
+
 size_t gcp_rects_rows_workspace_bytes(int64_t n);
 int64_t gcp_rects_rows_capacity(int64_t n);
 int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,

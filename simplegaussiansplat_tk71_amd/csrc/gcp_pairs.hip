@@ -33,9 +33,44 @@ using namespace gcp;
 
 constexpr int kRowsPerThread = 4;                 // 16 elements per thread
 constexpr int kElemTile = 1024 * kRowsPerThread;  // 4096 elements per block
-constexpr int kSlotRows = kElemTile;              // row records a tile may park: every element may start a row (the carry rows of a
-                                                  // chunked call, gs_model.py:611, are single pixels); a list of boxes parks ~ 4096 / box width
+constexpr int kSlotRowsMax = kElemTile;           // row records a tile may park at most: every element may start a row (the carry rows
+                                                  // of a chunked call, gs_model.py:611, are single pixels)
 constexpr int kRowTile = 1024;                    // rows per block in the second cut, 4 per thread
+
+// Where tile t parks its row records.  A list of boxes parks ~ 4096 / (box width) records per tile, so the tiles of the
+// boxes get `slot_rows` slots each (512 by default: 1 B of scratch per pair instead of 8; a tile that needs more marks the
+// list "not boxes at this capacity" and the caller repeats with more or sorts); only the tiles that hold the single-pixel
+// carry rows of a chunked call — [0, front_tiles) when they lead the list (gs_model.py:611), [back_tile0, n_tiles) when
+// they trail it (:636) — get one slot per element.  0 <= front_tiles <= back_tile0 <= n_tiles.
+struct SlotLayout {
+  i64 front_tiles, back_tile0;
+  int slot_rows;
+  __host__ __device__ i64 base(i64 t) const {
+    const i64 a = t < front_tiles ? t : front_tiles;
+    const i64 m = (t < back_tile0 ? t : back_tile0) - front_tiles;
+    const i64 c = t - back_tile0;
+    return a * kSlotRowsMax + (m > 0 ? m : 0) * slot_rows + (c > 0 ? c : 0) * kSlotRowsMax;
+  }
+  __host__ __device__ int cap(i64 t) const { return (t < front_tiles || t >= back_tile0) ? kSlotRowsMax : slot_rows; }
+};
+
+inline SlotLayout slot_layout(i64 n, i64 carry_front, i64 carry_back, int slot_rows) {
+  const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
+  SlotLayout L;
+  L.slot_rows = slot_rows < 1 ? 1 : (slot_rows > kSlotRowsMax ? kSlotRowsMax : slot_rows);
+  carry_front = carry_front < 0 ? 0 : (carry_front > n ? n : carry_front);
+  carry_back = carry_back < 0 ? 0 : (carry_back > n ? n : carry_back);
+  L.front_tiles = (carry_front + kElemTile - 1) / kElemTile;
+  L.back_tile0 = carry_back > 0 ? (n - carry_back) / kElemTile : n_tiles;
+  if (L.front_tiles > n_tiles) L.front_tiles = n_tiles;
+  if (L.back_tile0 < L.front_tiles) L.back_tile0 = L.front_tiles;
+  if (L.back_tile0 > n_tiles) L.back_tile0 = n_tiles;
+  return L;
+}
+
+// info[4] of the first cut: why the list cannot be walked as boxes
+constexpr int kNotBoxesRange = 1;     // a coordinate the walk cannot take (x >= 10000: the reference's key merges pixels; y >= 2^17), or more rows than the caller made room for
+constexpr int kNotBoxesSlots = 2;     // a tile parked more row records than its slots hold: repeat with more slots per tile, or sort
 
 // Ranks of the set bits of m[0..ROWS) inside the block: thread t of wave w holds the flags of the 4 consecutive items
 // w * 256 * ROWS + r * 256 + lane * 4 + k.  rank[r] = flags in front of the thread's row r; returns the block's count.
@@ -76,8 +111,9 @@ __device__ __forceinline__ int2 rect_at(const void* __restrict__ rects, i64 i) {
 }
 
 template <bool I64>
-__global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, int2* __restrict__ slots /*[tiles][kSlotRows]: {index, x | y << 14}*/,
-                                                         int* __restrict__ cnt, int* __restrict__ info /*[5]: rows, max x, max y, min, overflow*/) {
+__global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, const SlotLayout L,
+                                                         int2* __restrict__ slots /*tile t: [L.base(t), + L.cap(t)): {index, x | y << 14}*/,
+                                                         int* __restrict__ cnt, int* __restrict__ info /*[5]: rows, max x, max y, min, not-boxes flags*/) {
   __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 tile = blockIdx.x;
@@ -140,16 +176,19 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   }
   int rank[kRowsPerThread];
   const int count = block_ranks<kRowsPerThread>(m, rank, s_w);
-  int2* const mine = slots + tile * kSlotRows;
+  int2* const mine = slots + L.base(tile);
+  const bool fits = count <= L.cap(tile);  // block-uniform
+  if (fits) {
 #pragma unroll
-  for (int r = 0; r < kRowsPerThread; ++r) {
-    const i64 p = base + r * 256 + lane * 4;
-    int o = rank[r];
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const i64 p = base + r * 256 + lane * 4;
+      int o = rank[r];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if ((m[r] >> k) & 1u) {
-        mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
-        ++o;
+      for (int k = 0; k < 4; ++k) {
+        if ((m[r] >> k) & 1u) {
+          mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+          ++o;
+        }
       }
     }
   }
@@ -159,7 +198,9 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   if (lane == 0) { s_mx[w] = mx; s_my[w] = my; s_mn[w] = mn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    cnt[tile] = count;
+    cnt[tile] = fits ? count : 0;
+    // (look before the atomic, as below: a list that is not made of boxes overflows in EVERY tile)
+    if (!fits && !(__hip_atomic_load(info + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kNotBoxesSlots)) atomicOr(info + 4, kNotBoxesSlots);
     // Look before the atomic: 40 000 blocks hitting three words with an atomic each serialise at the L2 (1.1 of this
     // kernel's 1.4 ms when first written that way); the range settles after the first few blocks and the rest only read.
     const int bx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])), by = max(max(s_my[0], s_my[1]), max(s_my[2], s_my[3]));
@@ -167,7 +208,8 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
     // x >= 10000: the reference's pixel key y * 10000 + x (gs_model.py:538-541) then runs DIFFERENT pixels together —
     // (10000, 0) and (0, 1) share key 10000 — and only the key-based sort route reproduces its groups; the walk groups by
     // pixel.  y >= 2^17: does not fit the packed slot record (nor the reference's int32 key).
-    if (bx >= 10000 || by >= (1 << 17)) info[4] = 1;
+    if ((bx >= 10000 || by >= (1 << 17)) && !(__hip_atomic_load(info + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kNotBoxesRange))
+      atomicOr(info + 4, kNotBoxesRange);
     if (bx > __hip_atomic_load(info + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(info + 1, bx);
     if (by > __hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(info + 2, by);
     if (bn < __hip_atomic_load(info + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(info + 3, bn);
@@ -175,16 +217,19 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
 }
 
 // ---- cut 1, pass 2: the parked records to their final places -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
+__global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const SlotLayout L, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
                                                           i64 n_tiles, i64 row_capacity, int* __restrict__ row_start,
                                                           int2* __restrict__ row_xy, int* __restrict__ info) {
   const i64 tile = blockIdx.x;
-  if ((i64)off[n_tiles] + 1 > row_capacity) {  // more rows than the caller made room for: not a list of boxes, nothing is written
-    if (tile == 0 && threadIdx.x == 0) { info[0] = off[n_tiles]; info[4] = 1; }
+  const int flags = info[4];  // written by the launch before this one
+  if (flags != 0 || (i64)off[n_tiles] + 1 > row_capacity) {
+    // not a list the walk can take (coordinates, a tile with more rows than slots) or more rows than the caller made room
+    // for: nothing is written
+    if (tile == 0 && threadIdx.x == 0) { info[0] = off[n_tiles]; if (flags == 0) info[4] = kNotBoxesRange; }
     return;
   }
   const int o0 = off[tile], c = off[tile + 1] - o0;
-  const int2* const mine = slots + tile * kSlotRows;
+  const int2* const mine = slots + L.base(tile);
   for (int i = threadIdx.x; i < c; i += 256) {
     const int2 q = mine[i];
     row_start[o0 + i] = q.x;
@@ -197,13 +242,16 @@ __global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict
 }
 
 // ---- cut 2: rows -> rectangles (count, then write) -------------------------------------------------------------------------
+// rows_dev: NULL (n_rows is the host's count), or the first cut's info on the device — the grid then covers the row
+// CAPACITY, the count is info[0], and a list the first cut refused (info[4] != 0) has no rows at all.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__ row_start, const int2* __restrict__ row_xy, i64 n_rows,
-                                                         int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ rect_row,
-                                                         int* __restrict__ info) {
+                                                         const int* __restrict__ rows_dev, int* __restrict__ cnt, const int* __restrict__ off,
+                                                         int* __restrict__ rect_row, int* __restrict__ info) {
   __shared__ int s_w[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 tile = blockIdx.x;
+  if (rows_dev) n_rows = rows_dev[4] ? 0 : (i64)rows_dev[0];
   const i64 p = tile * kRowTile + (i64)w * 256 + lane * 4;
   unsigned m[1] = {0u};
   // rows p-1 .. p+3: first x, y and length (row_start has n_rows + 1 entries)
@@ -229,26 +277,72 @@ __global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if ((m[0] >> k) & 1u) rect_row[o++] = (int)(p + k);  // (as many rectangles as rows at most: the caller sized it so)
-  if (threadIdx.x == 0 && tile == (i64)gridDim.x - 1) {
+  if (threadIdx.x == 0 && tile == (n_rows > 0 ? (n_rows - 1) / kRowTile : 0)) {  // the block that holds the last row
     info[0] = off[tile] + count;
     rect_row[off[tile] + count] = (int)n_rows;  // sentinel
   }
 }
 
 // rectangle b = rows [rect_row[b], rect_row[b + 1]): its box, and where its pairs start in the list
-__global__ void k_rectangle_boxes(const int* __restrict__ rect_row, const int* __restrict__ row_start, const int2* __restrict__ row_xy,
-                                  i64 n_rects, i64 n, int* __restrict__ start_xy, int* __restrict__ end_xy, int* __restrict__ box_off) {
-  const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > n_rects) return;
-  if (b == n_rects) { box_off[b] = (int)n; return; }
-  const int r0 = rect_row[b], r1 = rect_row[b + 1];
-  const int2 q = row_xy[r0];
-  const int len = row_start[r0 + 1] - row_start[r0];
-  start_xy[2 * b] = q.x;
-  start_xy[2 * b + 1] = q.y;
-  end_xy[2 * b] = q.x + len - 1;
-  end_xy[2 * b + 1] = q.y + (r1 - r0) - 1;
-  box_off[b] = row_start[r0];
+// rects_dev: NULL (n_rects is the host's count), or the second cut's info on the device: the grid covers `capacity` + 1
+// entries and the count is rects_dev[0].  tile_cnt (with rects_dev): the number of 16x16 tiles every rectangle touches —
+// the boxes lie inside [0, max x] x [0, max y] by construction, so the binning's clamp is the identity and its counting
+// pass (gcp_bin_tiles_count) is this line — zeros behind the last rectangle, and their 64-bit total.
+__global__ __launch_bounds__(256) void k_rectangle_boxes(const int* __restrict__ rect_row, const int* __restrict__ row_start,
+                                                         const int2* __restrict__ row_xy, i64 n_rects, i64 n, const int* __restrict__ rects_dev,
+                                                         i64 capacity, int* __restrict__ start_xy, int* __restrict__ end_xy,
+                                                         int* __restrict__ box_off, int* __restrict__ tile_cnt,
+                                                         unsigned long long* __restrict__ total64) {
+  __shared__ unsigned long long s_total;
+  if (tile_cnt) {
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+  }
+  if (rects_dev) n_rects = rects_dev[0];
+  const bool fits = !rects_dev || n_rects <= capacity;  // more rectangles than the caller made room for: flagged by the finishing kernel
+  const i64 span = rects_dev ? capacity + 1 : n_rects + 1;
+  unsigned long long wide = 0;
+  // grid-stride (the fused cut launches few blocks: a few hundred atomics on the 64-bit total, not one per 256 rectangles)
+  for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < span; b += (i64)gridDim.x * blockDim.x) {
+    int c = 0;
+    if (fits && b < n_rects) {
+      const int r0 = rect_row[b], r1 = rect_row[b + 1];
+      const int2 q = row_xy[r0];
+      const int len = row_start[r0 + 1] - row_start[r0];
+      const int x1 = q.x + len - 1, y1 = q.y + (r1 - r0) - 1;
+      start_xy[2 * b] = q.x;
+      start_xy[2 * b + 1] = q.y;
+      end_xy[2 * b] = x1;
+      end_xy[2 * b + 1] = y1;
+      box_off[b] = row_start[r0];
+      c = ((x1 >> 4) - (q.x >> 4) + 1) * ((y1 >> 4) - (q.y >> 4) + 1);
+    } else if (fits && b == n_rects) {
+      box_off[b] = (int)n;
+    }
+    if (tile_cnt && b < capacity) tile_cnt[b] = c;
+    wide += (unsigned long long)c;
+  }
+  if (tile_cnt) {
+    if (wide) atomicAdd(&s_total, wide);  // integer adds: order-independent
+    __syncthreads();
+    if (threadIdx.x == 0 && s_total) atomicAdd(total64, s_total);
+  }
+}
+
+// info8 of gcp_rects_cut from what the stages left on the device
+__global__ void k_cut_finish(const int* __restrict__ info_rows /*[5]*/, const int* __restrict__ info_rects /*[2]*/,
+                             const unsigned long long* __restrict__ total64, i64 rect_capacity, int* __restrict__ info8) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int flags = info_rows[4];
+  const int n_rects = info_rects[0];
+  if (flags == 0 && (i64)n_rects > rect_capacity) flags |= 4;
+  const unsigned long long k = *total64;
+  if (flags == 0 && k > 0x7fffffffull) flags |= 8;
+  info8[0] = info_rows[0]; info8[1] = info_rows[1]; info8[2] = info_rows[2]; info8[3] = info_rows[3];
+  info8[4] = flags;
+  info8[5] = n_rects;
+  info8[6] = flags ? 0 : (int)k;
+  info8[7] = 0;
 }
 
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
@@ -257,31 +351,36 @@ inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 
 extern "C" {
 
-size_t gcp_rects_rows_workspace_bytes(int64_t n) {
-  const int64_t t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
-  return align256((size_t)t * kSlotRows * sizeof(int2)) + 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
+static size_t rows_ws_bytes(i64 n, const SlotLayout& L) {
+  const i64 t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
+  return align256((size_t)(L.base(t) + 1) * sizeof(int2)) + 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
 }
 
-static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy,
-                           int32_t* info, void* ws, size_t ws_bytes, void* stream_) {
+// every tile with one slot per element: a list of anything, 8 B of scratch per element
+size_t gcp_rects_rows_workspace_bytes(int64_t n) { return rows_ws_bytes(n, slot_layout(n, n, 0, kSlotRowsMax)); }
+
+// the first cut; `slots_out` (optional) receives the slot region's address — dead once this call's launches are through
+static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, const SlotLayout& L, int64_t row_capacity, int32_t* row_start,
+                           int32_t* row_xy, int32_t* info, void* ws, size_t ws_bytes, void* stream_, void** slots_out = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || n > 0x7fffffffLL || row_capacity < 1 || !info) return GCP_ERR_INVALID_ARGUMENT;
-  GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), overflow
+  GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), not-boxes flags
   GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info + 3), 0x7fffffff, 1, stream));   // min coordinate
   if (n == 0) return GCP_OK;
   if (!rects_xy || !row_start || !row_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
-  if (ws_bytes < gcp_rects_rows_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  if (ws_bytes < rows_ws_bytes(n, L)) return GCP_ERR_WORKSPACE;
   char* p = (char*)ws;
-  int2* slots = (int2*)p; p += align256((size_t)n_tiles * kSlotRows * sizeof(int2));
+  int2* slots = (int2*)p; p += align256((size_t)(L.base(n_tiles) + 1) * sizeof(int2));
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
-  if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, slots, cnt, info);
-  else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, slots, cnt, info);
+  if (slots_out) *slots_out = slots;
+  if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, cnt, info);
+  else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, cnt, info);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, (const int*)off, (i64)n, n_tiles,
+  hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, L, (const int*)off, (i64)n, n_tiles,
                      (i64)row_capacity, row_start, (int2*)row_xy, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
@@ -289,12 +388,12 @@ static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, int64_t r
 
 int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
                    void* ws, size_t ws_bytes, void* stream) {
-  return rects_rows_impl(rects_xy, false, n, row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
+  return rects_rows_impl(rects_xy, false, n, slot_layout(n, n, 0, kSlotRowsMax), row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
 }
 
 int gcp_rects_rows_i64(const int64_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,
                        void* ws, size_t ws_bytes, void* stream) {
-  return rects_rows_impl(rects_xy, true, n, row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
+  return rects_rows_impl(rects_xy, true, n, slot_layout(n, n, 0, kSlotRowsMax), row_capacity, row_start, row_xy, info, ws, ws_bytes, stream);
 }
 
 // rows a list may have and still be taken for boxes: a list of boxes has ~ n / (box width) of them, a list of unrelated
@@ -307,8 +406,9 @@ size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows) {
   return 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
 }
 
-int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
-                        size_t ws_bytes, void* stream_) {
+// n_rows: the row count, or — with rows_dev, the first cut's info on the device — the row CAPACITY the grid has to cover
+static int rows_rectangles_impl(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, const int* rows_dev, int32_t* rect_row,
+                                int32_t* info, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || n_rows > 0x7fffffffLL || !info) return GCP_ERR_INVALID_ARGUMENT;
   GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));  // rectangles, (unused)
@@ -319,15 +419,20 @@ int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t
   char* p = (char*)ws;
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
-  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, cnt,
-                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, rows_dev,
+                     cnt, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows,
+  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, rows_dev,
                      (int*)nullptr, (const int*)off, rect_row, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
+}
+
+int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream) {
+  return rows_rectangles_impl(row_start, row_xy, n_rows, nullptr, rect_row, info, ws, ws_bytes, stream);
 }
 
 int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const int32_t* row_xy, int64_t n_rects, int64_t n,
@@ -336,7 +441,84 @@ int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const
   if (n_rects < 0 || n < 0 || !box_off) return GCP_ERR_INVALID_ARGUMENT;
   if (n_rects > 0 && (!rect_row || !row_start || !row_xy || !start_xy || !end_xy)) return GCP_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)((n_rects + 1 + 255) / 256)), dim3(256), 0, stream, rect_row, row_start, (const int2*)row_xy,
-                     (i64)n_rects, (i64)n, start_xy, end_xy, box_off);
+                     (i64)n_rects, (i64)n, (const int*)nullptr, (i64)n_rects, start_xy, end_xy, box_off, (int*)nullptr,
+                     (unsigned long long*)nullptr);
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+// ---- the whole cut in one call, nothing read back in between ------------------------------------------------------------------
+// rows -> rectangles -> boxes -> tiles per box -> their prefix sums, every count handed on in device memory; the caller reads
+// info8 ONCE and knows everything the binning and the walk need.  Scratch: the slot region (8 B x slot_rows per 4096-pair
+// tile; the rectangle list of the second cut re-uses it), the rows (12 B each, at most one per slot), a few words per tile —
+// with 512 slots per tile 2.5 B per pair, plus 28 B per rectangle of capacity in the caller's arrays.
+static i64 cut_row_capacity(i64 n, const SlotLayout& L) { return L.base((n + kElemTile - 1) / kElemTile) + 1; }
+
+struct CutWs {
+  size_t rows_ws, row_start, row_xy, rect_ws, tile_cnt, scan_ws, info, total;
+};
+static CutWs cut_ws_layout(i64 n, const SlotLayout& L, i64 rect_capacity) {
+  const i64 rc = cut_row_capacity(n, L);
+  CutWs w;
+  size_t o = 0;
+  w.rows_ws = o; o += align256(rows_ws_bytes(n, L));
+  w.row_start = o; o += align256((size_t)(rc + 1) * sizeof(int));
+  w.row_xy = o; o += align256((size_t)rc * sizeof(int2));
+  w.rect_ws = o; o += align256(gcp_rows_rectangles_workspace_bytes(rc));
+  w.tile_cnt = o; o += align256((size_t)(rect_capacity + 1) * sizeof(int));
+  w.scan_ws = o; o += align256(gcp_scan_i32_workspace_bytes(rect_capacity + 1));
+  w.info = o; o += 256;   // int[5] rows info, int[2] rectangles info at +32
+  w.total = o; o += 256;  // 64-bit total of the tile counts
+  return w;
+}
+
+size_t gcp_rects_cut_workspace_bytes(int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows, int64_t rect_capacity) {
+  if (n < 0 || rect_capacity < 0) return 0;
+  return cut_ws_layout(n, slot_layout(n, carry_front, carry_back, slot_rows), rect_capacity).total + 256;
+}
+
+int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows,
+                  int64_t rect_capacity, int32_t* start_xy, int32_t* end_xy, int32_t* box_off, int32_t* tile_off, int32_t* info8,
+                  void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || n > 0x7fffffffLL || rect_capacity < 1 || rect_capacity > 0x7ffffff0LL || !info8) return GCP_ERR_INVALID_ARGUMENT;
+  GCP_HIP(hipMemsetAsync(info8, 0, 8 * sizeof(int), stream));
+  if (n == 0) {
+    GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info8 + 3), 0x7fffffff, 1, stream));
+    if (box_off) GCP_HIP(hipMemsetAsync(box_off, 0, sizeof(int), stream));
+    if (tile_off) GCP_HIP(hipMemsetAsync(tile_off, 0, sizeof(int), stream));
+    return GCP_OK;
+  }
+  if (!rects_xy || !start_xy || !end_xy || !box_off || !tile_off || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  const SlotLayout L = slot_layout(n, carry_front, carry_back, slot_rows);
+  const CutWs w = cut_ws_layout(n, L, rect_capacity);
+  if (ws_bytes < w.total + 256 || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
+  char* const base = (char*)ws;
+  int* const row_start = (int*)(base + w.row_start);
+  int* const row_xy = (int*)(base + w.row_xy);
+  int* const info_rows = (int*)(base + w.info);
+  int* const info_rects = info_rows + 8;
+  unsigned long long* const total64 = (unsigned long long*)(base + w.total);
+  int* const tile_cnt = (int*)(base + w.tile_cnt);
+  const i64 row_cap = cut_row_capacity(n, L);
+  void* slots = nullptr;
+  int st = rects_rows_impl(rects_xy, rects_are_int64 != 0, n, L, row_cap, row_start, row_xy, info_rows, base + w.rows_ws, rows_ws_bytes(n, L), stream_, &slots);
+  if (st != GCP_OK) return st;
+  // the rectangle list (one int per rectangle, at most one per row, + the sentinel) re-uses the slot region: its records
+  // have all been moved to the rows by now (8 B per slot there, 4 B per row here)
+  int* const rect_row = (int*)slots;
+  st = rows_rectangles_impl(row_start, row_xy, row_cap, info_rows, rect_row, info_rects, base + w.rect_ws, gcp_rows_rectangles_workspace_bytes(row_cap), stream_);
+  if (st != GCP_OK) return st;
+  GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
+  const i64 box_blocks = (rect_capacity + 1 + 255) / 256 < 1024 ? (rect_capacity + 1 + 255) / 256 : 1024;
+  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)box_blocks), dim3(256), 0, stream, (const int*)rect_row,
+                     (const int*)row_start, (const int2*)row_xy, (i64)0, (i64)n, (const int*)info_rects, (i64)rect_capacity, start_xy, end_xy,
+                     box_off, tile_cnt, total64);
+  GCP_HIP(hipGetLastError());
+  st = gcp_exclusive_scan_i32(tile_cnt, tile_off, rect_capacity, base + w.scan_ws, gcp_scan_i32_workspace_bytes(rect_capacity + 1), stream_);
+  if (st != GCP_OK) return st;
+  hipLaunchKernelGGL(k_cut_finish, dim3(1), dim3(64), 0, stream, (const int*)info_rows, (const int*)info_rects, (const unsigned long long*)total64,
+                     (i64)rect_capacity, info8);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

@@ -1052,31 +1052,46 @@ __device__ __forceinline__ void walk_count_dropped(bool drop, unsigned off, int*
     dm &= ~same;
   }
 }
-template <int MODE, bool WIDE, bool COUNT>
-__device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict__ out, float& acc, int* __restrict__ dropped) {
+// OUT: what a pair receives.  kWalkInclusive: its inclusive value (gs_model.py:555); kWalkCount: the same, and the zeros
+// written are counted per 4096 pairs; kWalkFinal: the FINAL value of _create_alpha_brend — inclusive / self (cumprod,
+// gs_model.py:562) or inclusive - self (cumsum, :564): the pair's own value is in a register anyway, and it is the same
+// fp32 division / subtraction the compaction pass would do on the stored inclusive value, so the bits are the same — while
+// the `!= 0` test of :560 is taken on the inclusive value here: a pair whose inclusive value is exactly 0 clears its byte of
+// `keep` (pre-set to 1 by the launcher) and is counted.  A scene that drops nothing is finished after this kernel.
+constexpr int kWalkInclusive = 0, kWalkCount = 1, kWalkFinal = 2;
+template <int MODE, bool WIDE, int OUT>
+__device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict__ out, float& acc, int* __restrict__ dropped,
+                                          unsigned char* __restrict__ keep) {
 #pragma unroll
   for (int u = 0; u < kWalkBatch; ++u) {
     bool drop = false;
     if (b.in[u]) {
       acc = (MODE == 0) ? acc * b.v[u] : acc + b.v[u];
       drop = acc == 0.0f;  // NaN is kept, as `!= 0` keeps it
+      const float res = (OUT != kWalkFinal) ? acc : (MODE == 0 ? acc / b.v[u] : acc - b.v[u]);
 #if (GCP_WALK_DBG & 2)
       if (acc == 12345.678f)
 #endif
       {
-        if (WIDE) out[b.off[u]] = acc;
-        else *(float*)((char*)out + b.off[u]) = acc;
+        if (WIDE) out[b.off[u]] = res;
+        else *(float*)((char*)out + b.off[u]) = res;
       }
     }
-    if (COUNT) walk_count_dropped<WIDE>(drop, b.off[u], dropped);
+    if (OUT != kWalkInclusive) {
+      if (OUT == kWalkFinal && __ballot(drop) != 0ull) {  // wave-uniform: no store instruction at all where nothing drops
+        if (drop) keep[WIDE ? b.off[u] : (b.off[u] >> 2)] = 0;
+      }
+      walk_count_dropped<WIDE>(drop, b.off[u], dropped);
+    }
   }
 }
 
-template <int MODE, bool WIDE, bool COUNT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
+template <int MODE, bool WIDE, int OUT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 // (pinned to eight waves per SIMD the byte-offset form fits 63 VGPRs without a spill — and runs no faster: 0.62 ms either way)
 __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
                                                           const float* __restrict__ x, float* __restrict__ out,
-                                                          int* __restrict__ dropped, int n_tiles, int xcd_remap) {
+                                                          int* __restrict__ dropped, unsigned char* __restrict__ keep, int n_tiles,
+                                                          int xcd_remap) {
   // a staged entry: x = position of the tile's first pixel in the entry's box run (box_off + (tile_y0 - y0) * width +
   // (tile_x0 - x0), may lie before the run), y = box width — both in bytes unless WIDE —, z = the box as bits over the
   // tile's columns (0-15) and rows (16-31).  A lane's pair is x + row * y + column, and it is in the box when both of
@@ -1134,12 +1149,12 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
       WalkBatch A, B;
       walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
       for (;;) {
-        if (!hits) { walk_fold<MODE, WIDE, COUNT>(A, out, acc, dropped); break; }
+        if (!hits) { walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep); break; }
         walk_load<MODE, WIDE>(B, hits, s_ent, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE, COUNT>(A, out, acc, dropped);
-        if (!hits) { walk_fold<MODE, WIDE, COUNT>(B, out, acc, dropped); break; }
+        walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
+        if (!hits) { walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
         walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE, COUNT>(B, out, acc, dropped);
+        walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
       }
     }
   }
@@ -1303,6 +1318,84 @@ __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ incl,
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (p + k < n) keep[p + k] = (unsigned char)((m[r] >> k) & 1u);
+    }
+  }
+}
+
+// ---- the compaction that is left when the walk has written final values: only where something was dropped ---------------
+// per-tile kept counts from the keep bytes of [begin, end) (tile t = elements [begin + 4096 t, ...)): 1 B per element
+__global__ __launch_bounds__(256) void k_count_keep(const unsigned char* __restrict__ keep, i64 n, int* __restrict__ cnt) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 p = (i64)blockIdx.x * kCompactTile + (i64)threadIdx.x * 16;
+  int c = 0;
+  if ((((uintptr_t)keep) & 15u) == 0 && p + 15 < n) {
+    const uint4 q = *reinterpret_cast<const uint4*>(keep + p);
+    c = __builtin_popcount(q.x & 0x01010101u) + __builtin_popcount(q.y & 0x01010101u) + __builtin_popcount(q.z & 0x01010101u) +
+        __builtin_popcount(q.w & 0x01010101u);
+  } else {
+    for (int k = 0; k < 16; ++k) c += (p + k < n && keep[p + k]) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) s_w[w] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// kept values of [begin, end) to their ranks (tile offsets from the exclusive scan of the counts + ranks inside the tile)
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_compact_kept(const float* __restrict__ vals, const unsigned char* __restrict__ keep, i64 n,
+                                                      const int* __restrict__ off, float* __restrict__ out) {
+  __shared__ int s_w[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 base = (i64)blockIdx.x * kCompactTile + (i64)w * 1024;
+  float v[4][4];
+  unsigned m[4];
+  int c[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    m[r] = 0u;
+    if (VEC && p + 3 < n) {
+      const float4 a = *reinterpret_cast<const float4*>(vals + p);
+      v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w;
+      const unsigned q = *reinterpret_cast<const unsigned*>(keep + p);  // bytes 0 / 1, memory order
+      m[r] = (q & 1u) | ((q >> 7) & 2u) | ((q >> 14) & 4u) | ((q >> 21) & 8u);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[r][k] = (p + k < n) ? vals[p + k] : 0.0f;
+        m[r] |= ((p + k < n && keep[p + k]) ? 1u : 0u) << k;
+      }
+    }
+    c[r] = __builtin_popcount(m[r]);
+  }
+  int before[4];
+  int wtot = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int inc = wave_incl_scan_i(c[r]);
+    before[r] = wtot + inc - c[r];
+    wtot += __builtin_amdgcn_readlane(inc, 63);
+  }
+  if (lane == 0) s_w[w] = wtot;
+  __syncthreads();
+  int woff = off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < w) woff += s_w[j];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int o = woff + before[r];
+    if (m[r] == 0xfu) {
+      typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+      float4_u q;
+      q.x = v[r][0]; q.y = v[r][1]; q.z = v[r][2]; q.w = v[r][3];
+      *reinterpret_cast<float4_u*>(out + o) = q;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((m[r] >> k) & 1u) out[o++] = v[r][k];
     }
   }
 }
@@ -1727,17 +1820,21 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
   return GCP_OK;
 }
 
-int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
-                         const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                         float* inclusive, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream_) {
+// keep != NULL: the FINAL form (values + keep mask + zero counts); else the inclusive form, counting when `dropped_per_tile`
+static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                     const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x, float* out,
+                     int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, uint8_t* keep, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
   if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2 || n_pairs < 0 || n_pairs > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
-  if (n_gauss == 0 || n_pairs == 0) return GCP_OK;
-  if (!start_xy || !end_xy || !tile_list || !box_off || !x || !inclusive || x == inclusive) return GCP_ERR_INVALID_ARGUMENT;
+  if (keep && !dropped_per_tile && n_pairs > 0) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_pairs == 0) return GCP_OK;
+  if (keep) GCP_HIP(hipMemsetAsync(keep, 1, (size_t)n_pairs, stream));  // every pair kept until the walk finds its inclusive value 0
   if (dropped_per_tile)
     GCP_HIP(hipMemsetAsync(dropped_per_tile, 0, (size_t)((n_pairs + kCompactTile - 1) / kCompactTile) * sizeof(int), stream));
+  if (n_gauss == 0) return GCP_OK;
+  if (!start_xy || !end_xy || !tile_list || !box_off || !x || !out || x == out) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
   static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 1; }();
   // pair positions as 32-bit byte offsets while the list is no longer than 2^30 pairs (GCP_WALK_WIDE=1 forces the other form)
@@ -1746,21 +1843,87 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
   // a pair's position is formed with ONE 24-bit multiply (row in the tile) x (box width, in bytes unless WIDE): a box can be
   // as wide as the image, so the image has to fit — 2^22 columns in the byte-offset form, 2^24 in the element form
   if ((int64_t)width + 1 >= (wide ? (1LL << 24) : (1LL << 22))) return GCP_ERR_INVALID_ARGUMENT;
-  const bool count = dropped_per_tile != nullptr;
+  const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);
-#define GCP_WALK(M, W_, C_) \
-  hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, C_>), grid, block, 0, stream, a, box_off, x, inclusive, dropped_per_tile, n_tiles, xcd_remap)
-#define GCP_WALK_MODE(M)                                                    \
-  do {                                                                      \
-    if (wide) { if (count) GCP_WALK(M, true, true); else GCP_WALK(M, true, false); }  \
-    else { if (count) GCP_WALK(M, false, true); else GCP_WALK(M, false, false); }     \
+#define GCP_WALK(M, W_, O_) \
+  hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, O_>), grid, block, 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
+#define GCP_WALK_OUT(M, W_)                                  \
+  do {                                                       \
+    if (out_mode == kWalkFinal) GCP_WALK(M, W_, kWalkFinal); \
+    else if (out_mode == kWalkCount) GCP_WALK(M, W_, kWalkCount); \
+    else GCP_WALK(M, W_, kWalkInclusive);                    \
   } while (0)
+#define GCP_WALK_MODE(M) do { if (wide) GCP_WALK_OUT(M, true); else GCP_WALK_OUT(M, false); } while (0)
   if (mode == 0) GCP_WALK_MODE(0);
   else if (mode == 1) GCP_WALK_MODE(1);
   else GCP_WALK_MODE(2);
 #undef GCP_WALK_MODE
+#undef GCP_WALK_OUT
 #undef GCP_WALK
+  GCP_HIP(hipGetLastError());
+  return GCP_OK;
+}
+
+int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                         const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
+                         float* inclusive, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream) {
+  if (n_gauss == 0) return (n_gauss < 0 || n_pairs < 0 || mode < 0 || mode > 2 || width < 0 || height < 0 || !tile_start) ? GCP_ERR_INVALID_ARGUMENT : GCP_OK;
+  return walk_impl(start_xy, end_xy, n_gauss, width, height, tile_start, tile_list, box_off, x, inclusive, n_pairs, mode,
+                   dropped_per_tile, nullptr, stream);
+}
+
+int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
+                           const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
+                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream) {
+  if (n_pairs > 0 && (!keep || !dropped_per_tile)) return GCP_ERR_INVALID_ARGUMENT;
+  return walk_impl(start_xy, end_xy, n_gauss, width, height, tile_start, tile_list, box_off, x, values, n_pairs, mode,
+                   dropped_per_tile, keep, stream);
+}
+
+size_t gcp_compact_kept_workspace_bytes(int64_t n) { return gcp_compact_workspace_bytes(n); }
+
+int gcp_compact_kept_count(const uint8_t* keep, const int32_t* dropped_per_tile, int64_t n_total, int64_t begin, int64_t end,
+                           int32_t* count_dev, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (begin < 0 || end < begin || end > n_total || end - begin > 0x7fffffffLL || !count_dev) return GCP_ERR_INVALID_ARGUMENT;
+  const i64 n = end - begin;
+  if (n == 0) {
+    GCP_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), stream));
+    return GCP_OK;
+  }
+  if (!keep || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_compact_kept_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  const i64 nb = (n + kCompactTile - 1) / kCompactTile;
+  char* p = (char*)ws;
+  int* cnt = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  int* off = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  int* sws = (int*)p;
+  // the walk's own counts serve when the range's tiles are the array's tiles and its last tile is not cut short by `end`
+  if (dropped_per_tile && begin % kCompactTile == 0 && (end == n_total || end % kCompactTile == 0))
+    hipLaunchKernelGGL(k_counts_from_dropped, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream,
+                       dropped_per_tile + begin / kCompactTile, n, nb, cnt);
+  else hipLaunchKernelGGL(k_count_keep, dim3((unsigned)nb), dim3(256), 0, stream, keep + begin, n, cnt);
+  GCP_HIP(hipGetLastError());
+  const int st = launch_excl_scan(cnt, off, nb, sws, stream);
+  if (st != GCP_OK) return st;
+  GCP_HIP(hipMemcpyAsync(count_dev, off + nb, sizeof(int), hipMemcpyDeviceToDevice, stream));
+  return GCP_OK;
+}
+
+int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, const void* ws,
+                           size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (begin < 0 || end < begin || end - begin > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
+  const i64 n = end - begin;
+  if (n == 0) return GCP_OK;
+  if (!values_in || !keep || !values_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (ws_bytes < gcp_compact_kept_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
+  const i64 nb = (n + kCompactTile - 1) / kCompactTile;
+  const int* off = (const int*)((const char*)ws + align256((size_t)(nb + 1) * sizeof(int)));
+  const bool vec = (((uintptr_t)(values_in + begin)) & 15u) == 0 && (((uintptr_t)(keep + begin)) & 3u) == 0;
+  if (vec) hipLaunchKernelGGL((k_compact_kept<true>), dim3((unsigned)nb), dim3(256), 0, stream, values_in + begin, keep + begin, n, off, values_out);
+  else hipLaunchKernelGGL((k_compact_kept<false>), dim3((unsigned)nb), dim3(256), 0, stream, values_in + begin, keep + begin, n, off, values_out);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

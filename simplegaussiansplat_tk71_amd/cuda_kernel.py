@@ -262,25 +262,27 @@ class PreparedRects:
         S, mask = grad_cumsum(prep, grad)
 
     `boxes` is None when the list is not a concatenation of boxes; the calls then sort (`rects` is kept for that).
-    carry_rows: the number of `cutting_number` rows the list starts (or, for `grad_cumsum`, ends) with in a chunked call
-    (gs_model.py:611, :636): single pixels, which are cut into one-pixel-wide rectangles and walked like the boxes."""
+    carry_rows: the number of `cutting_number` rows the list starts — or, carry_at_end (`grad_cumsum`), ends — with in a
+    chunked call (gs_model.py:611, :636): single pixels, which are cut into one-pixel-wide rectangles and walked like the
+    boxes."""
 
-    def __init__(self, rects, carry_rows=0):
+    def __init__(self, rects, carry_rows=0, carry_at_end=False):
         self.rects = rects
         self.shape = rects.shape
         with torch.no_grad():
-            rb = _raster.rects_to_boxes(rects, carry_rows=carry_rows)
+            rb = _raster.rects_to_boxes(rects, carry_rows=carry_rows, carry_at_end=carry_at_end)
             if rb is not None and (rb.width + 1) * (rb.height + 1) > _MAX_WALK_PIXELS:
                 rb = None
             self.boxes = rb
-            self.bins = _raster.bin_tiles(rb.start, rb.end, rb.width, rb.height) if rb is not None else None
+            self.bins = rb.bin() if rb is not None else None
 
 
 def _rects_as_boxes(rects, values, flag, cutting_number=None):
     """The boxes route from nothing but the rect list; None if the list is not a concatenation of boxes."""
     if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
         raise ValueError(flag)
-    prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects, carry_rows=int(cutting_number) if cutting_number else 0)
+    prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects, carry_rows=int(cutting_number) if cutting_number else 0,
+                                                                       carry_at_end=flag == "cumsum_reverse")
     rb, bins = prep.boxes, prep.bins
     if rb is None:
         return None
@@ -288,13 +290,26 @@ def _rects_as_boxes(rects, values, flag, cutting_number=None):
     n = values.numel()
     if n != int(prep.shape[0]):
         raise RuntimeError(f"values: {n} rows, rects has {int(prep.shape[0])}")
+    return _walk_and_finish(bins, rb.start, rb.end, rb.box_off, values, flag, cutting_number)
+
+
+def _walk_and_finish(bins, start, end, box_off, values, flag, cutting_number=None):
+    """Walk + tail of _create_alpha_brend (gs_model.py:546-564) from binned boxes.  The walk writes the FINAL values
+    (inclusive / self, inclusive - self) and clears the mask byte of every pair whose inclusive value is exactly 0; one
+    device->host read of the kept count — the one that sizes the result — decides: nothing dropped (the usual case: a
+    factor 1 - alpha G is 0 only for alpha G == 1, a product underflows only behind ~100 opaque layers) and the walk's
+    output IS the result, else one pass moves the kept values together."""
+    n = values.numel()
     mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
-    # the walk counts the zeros it writes (per 4096 pairs): the compaction does not read the array once more to find them
-    inclusive, dropped = _raster.scan_boxes(bins, rb.start, rb.end, rb.box_off, values, mode, count_dropped=True)
     cut = int(cutting_number) if cutting_number else 0
-    begin, end = (0, n - cut) if flag == "cumsum_reverse" else (cut, n)
-    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, begin, end, dropped=dropped)
-    return [values_out, keep]
+    begin, stop = (0, n - cut) if flag == "cumsum_reverse" else (cut, n)
+    if n == 0 or bins.n_tile_pairs == 0:
+        if n:
+            raise RuntimeError("values: the boxes expand to no pair at all")
+        return [values.new_empty(0), torch.zeros(0, dtype=torch.bool, device=values.device)]
+    final, keep, dropped = _raster.finish_boxes(bins, start, end, box_off, values, mode)
+    values_out, mask = _raster.compact_kept(final, keep, dropped, max(0, min(begin, n)), max(0, stop))
+    return [values_out, mask]
 
 
 def _scan_unsort_compact(sorted_key, index, anti_opacity, flag, cutting_number=None):
@@ -328,10 +343,7 @@ def _scan_boxes_compact(startpoint, endpoint, values, image_width, image_height,
     m = int(box_off[-1].item())
     if values.numel() != m:
         raise RuntimeError(f"values: {values.numel()} rows, but the boxes expand to {m} pairs")
-    mode = {"cumprod": 0, "cumsum": 1, "cumsum_reverse": 2}[flag]
-    inclusive, dropped = _raster.scan_boxes(bins, startpoint, endpoint, box_off, values, mode, count_dropped=True)
-    values_out, keep = _raster.compact_finish(inclusive, values, 0 if flag == "cumprod" else 1, dropped=dropped)
-    return [values_out, keep]
+    return _walk_and_finish(bins, startpoint, endpoint, box_off, values, flag)
 
 
 def create_alpha_brend_boxes(startpoint, endpoint, anti_opacity, image_width, image_height, flag="cumprod"):

@@ -62,12 +62,14 @@ class TileBins:
         return bool(self.info[1].item()) if self.info is not None else False
 
 
-def bin_tiles(startpoint, endpoint, width, height, capacity=None):
+def bin_tiles(startpoint, endpoint, width, height, capacity=None, counted=None):
     """startpoint/endpoint: int [N,2] (x,y) inclusive boxes in depth order.
 
     capacity=None: two calls with one device->host read of the entry count K in between (exactly sized buffers).
     capacity=K_max: ONE call, no read-back, graph-capturable; `bins.n_tile_pairs` is then the capacity, the true count
-    stays on the device (`bins.info`) and `bins.overflowed()` tells after the fact whether the bound was too small."""
+    stays on the device (`bins.info`) and `bins.overflowed()` tells after the fact whether the bound was too small.
+    counted=(tile_off int32[N+1], K): the counting pass has been done already (`rects_to_boxes` does it while it cuts the
+    list): the second call alone, nothing read back."""
     start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
     end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
     n = start.size(0)
@@ -78,6 +80,22 @@ def bin_tiles(startpoint, endpoint, width, height, capacity=None):
     tx, ty = ctypes.c_int32(0), ctypes.c_int32(0)
     _lib.check(lib.gcp_tile_grid(width, height, ctypes.byref(tx), ctypes.byref(ty)), "gcp_tile_grid")
     n_tiles = tx.value * ty.value
+    if counted is not None:
+        _require(capacity is None, "bin_tiles: `counted` and `capacity` exclude each other")
+        tile_off, K = counted
+        tile_off = _dev_tensor(tile_off, "tile_off", torch.int32)
+        K = int(K)
+        _require(tile_off.numel() >= n + 1 and K >= 0, "counted: expected (int32[N + 1] prefix sums, their total)")
+        with torch.cuda.device(dev):
+            tile_start = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            tile_list = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+            ws = torch.empty(lib.gcp_bin_workspace_bytes(n, K), dtype=torch.uint8, device=dev)
+            _lib.check(
+                lib.gcp_bin_tiles_fill(start.data_ptr(), end.data_ptr(), n, width, height, tile_off.data_ptr(), K,
+                                       tile_start.data_ptr(), tile_list.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                "gcp_bin_tiles_fill",
+            )
+        return TileBins(width, height, n, K, tx.value, ty.value, tile_off, tile_start, tile_list[:K])
     if capacity is not None:
         cap = int(capacity)
         _require(cap >= 1, "capacity: must be >= 1")
@@ -307,6 +325,68 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode, count_dropped=
     return (out, dropped) if count_dropped else out
 
 
+def finish_boxes(bins, startpoint, endpoint, box_off, values, mode):
+    """The walk of `scan_boxes` writing the FINAL values of _create_alpha_brend (gs_model.py:557-564) instead of the inclusive
+    ones: -> (final f32[M] = inclusive / self (mode 0) or inclusive - self (modes 1, 2), keep uint8[M] = inclusive != 0,
+    dropped int32[ceil(M / 4096)]).  Hand all three to `compact_kept`: when nothing was dropped they ARE the result."""
+    start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
+    end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
+    x = _dev_tensor(values, "values", torch.float32)
+    off = _dev_tensor(box_off, "box_off", torch.int32)
+    _require(x.dim() == 1, "values: expected a 1-D tensor")
+    _require(off.numel() >= bins.n_gauss + 1, "box_off: expected n_gauss + 1 offsets")
+    m = x.numel()
+    out = torch.empty_like(x)
+    keep = torch.empty(m, dtype=torch.uint8, device=x.device)
+    dropped = torch.empty((m + 4095) // 4096, dtype=torch.int32, device=x.device)
+    if m == 0:
+        return out, keep, dropped
+    _require(bins.n_tile_pairs > 0, "values: the boxes expand to no pair at all")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().gcp_pairs_finish_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
+                                                      bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
+                                                      out.data_ptr(), keep.data_ptr(), m, int(mode), dropped.data_ptr(),
+                                                      _stream(x.device)), "gcp_pairs_finish_boxes")
+    return out, keep, dropped
+
+
+def compact_kept(final, keep, dropped=None, begin=0, end=None):
+    """[values, mask] of _create_alpha_brend from what `finish_boxes` wrote, rows [begin, end) (the `cutting_number` slice,
+    gs_model.py:557-559): ONE device->host read — the kept count, which sizes the result as the reference's `output[mask]`
+    does — and, only if something was dropped, one pass that moves the kept values together.  When nothing was dropped the
+    returned tensors are views of `final` and `keep`."""
+    fin = _dev_tensor(final, "final", torch.float32)
+    kp = _dev_tensor(keep, "keep", torch.uint8)
+    _require(fin.dim() == 1 and kp.shape == fin.shape, "final / keep: expected two 1-D tensors of one length")
+    m = fin.numel()
+    end = m if end is None else int(end)
+    begin = int(begin)
+    _require(0 <= begin <= end <= m, "compact_kept: bad row range")
+    n = end - begin
+    dev = fin.device
+    mask = kp[begin:end].view(torch.bool)
+    if n == 0:
+        return fin[begin:end], mask
+    lib = _lib.load()
+    if dropped is not None:
+        dropped = _dev_tensor(dropped, "dropped", torch.int32)
+        _require(dropped.numel() == (m + 4095) // 4096, "dropped: expected one count per 4096 rows")
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_compact_kept_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_compact_kept_count(kp.data_ptr(), dropped.data_ptr() if dropped is not None else None, m, begin, end,
+                                              count.data_ptr(), ws.data_ptr(), ws.numel(), st), "gcp_compact_kept_count")
+        kept = int(count.item())
+        if kept == n:
+            return fin[begin:end], mask
+        values = torch.empty(kept, dtype=torch.float32, device=dev)
+        if kept:
+            _lib.check(lib.gcp_compact_kept_write(fin.data_ptr(), kp.data_ptr(), begin, end, values.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                       "gcp_compact_kept_write")
+    return values, mask
+
+
 @dataclass
 class RectBoxes:
     """A rect list cut back into rectangles (`rects_to_boxes`): the boxes, in list order, that expand to it."""
@@ -315,15 +395,62 @@ class RectBoxes:
     box_off: torch.Tensor  # int32[R+1]: first pair of every rectangle, [-1] = M
     width: int             # largest x in the list
     height: int            # largest y
+    tile_off: torch.Tensor = None  # int32[R+1]: the binning's counting pass, done with the cut (None: not done)
+    n_tile_pairs: int = None       # its total K
+
+    def bin(self):
+        """The rectangles binned into 16x16 tiles (`bin_tiles`), without a second counting pass where the cut has done it."""
+        counted = (self.tile_off, self.n_tile_pairs) if self.tile_off is not None else None
+        return bin_tiles(self.start, self.end, self.width, self.height, counted=counted)
 
 
-def rects_to_boxes(rects, min_mean_size=8, carry_rows=0):
+CUT_SLOT_ROWS = 512   # row records a 4096-pair tile may park in the one-call cut: boxes of 8 columns and more
+CUT_MIN_RECT = 64     # pairs per rectangle its arrays are sized for (a list with smaller boxes takes the step-by-step cut)
+
+
+def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size):
+    """gcp_rects_cut: rows, rectangles, boxes and the binning's counts with ONE device->host read.  Returns a RectBoxes, None
+    (not a list the walk can take: sort) or "retry" (more rows per tile or smaller rectangles than this attempt made room
+    for: the step-by-step cut decides)."""
+    lib = _lib.load()
+    m = r.size(0)
+    dev = r.device
+    cap = (m - carry_front - carry_back) // CUT_MIN_RECT + carry_front + carry_back + 16
+    with torch.cuda.device(dev):
+        st = _stream(dev)
+        start = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+        end = torch.empty(cap, 2, dtype=torch.int32, device=dev)
+        box_off = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+        tile_off = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+        info = torch.empty(8, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_rects_cut_workspace_bytes(m, carry_front, carry_back, CUT_SLOT_ROWS, cap), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_rects_cut(r.data_ptr(), 1 if i64 else 0, m, carry_front, carry_back, CUT_SLOT_ROWS, cap, start.data_ptr(),
+                                     end.data_ptr(), box_off.data_ptr(), tile_off.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                   "gcp_rects_cut")
+        n_rows, max_x, max_y, mn, flags, n_rects, k, _ = info.tolist()
+        del ws
+    _require(mn >= 0, "rects: coordinates must lie in [0, 2^31) (negative ones are not supported)")
+    if flags & 1:
+        return None
+    if flags:
+        return "retry"
+    if n_rects * min_mean_size > m:
+        return None
+    return RectBoxes(start[:n_rects], end[:n_rects], box_off[: n_rects + 1], int(max_x), int(max_y), tile_off[: n_rects + 1], int(k))
+
+
+def rects_to_boxes(rects, min_mean_size=8, carry_rows=0, carry_at_end=False, one_call=True):
     """Cut the reference's rect list (int [M,2] (x, y), gs_model.py:480-482) back into the row-major rectangles it is a
     concatenation of (csrc/gcp_pairs.hip).  Works on any list; returns None when the list does not look like boxes at all
     (more than one row per two pairs, or fewer than `min_mean_size` pairs per rectangle on average: the caller sorts
-    instead).  carry_rows: how many single-pixel carry rows the list starts or ends with (a chunked call's
+    instead).  carry_rows: how many single-pixel carry rows the list starts — or, carry_at_end, ends — with (a chunked call's
     `cutting_number` rows, gs_model.py:611, :636 — sorted unique pixels, which come out as one-pixel-wide rectangles): they
-    are allowed for on top.  Two device->host reads (row and rectangle counts)."""
+    are allowed for on top.
+
+    Default: the whole cut AND the binning's counting pass in one call (gcp_rects_cut) with ONE device->host read and 2.5 B of
+    scratch per pair — sized for what the reference's lists are (rows of 8 pixels and more, rectangles of 64 pairs and more
+    on average).  A list of smaller boxes takes the step-by-step cut (three reads, 14 B of scratch per pair; one_call=False
+    forces it)."""
     # int64 lists — what the reference's own make_rect_points_parallel returns (uitility.py:336-366) — are read as they are
     i64 = isinstance(rects, torch.Tensor) and rects.dtype == torch.int64
     r = _dev_tensor(rects, "rects", torch.int64 if i64 else torch.int32, (2,))
@@ -335,6 +462,10 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0):
     lib = _lib.load()
     cut = lib.gcp_rects_rows_i64 if i64 else lib.gcp_rects_rows
     carry_rows = min(max(int(carry_rows), 0), m)
+    if one_call:
+        out = _cut_rects_once(r, i64, 0 if carry_at_end else carry_rows, carry_rows if carry_at_end else 0, min_mean_size)
+        if not isinstance(out, str):
+            return out
     cap = min(carry_rows + lib.gcp_rects_rows_capacity(m - carry_rows), m + 1)
     with torch.cuda.device(dev):
         st = _stream(dev)

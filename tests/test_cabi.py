@@ -166,7 +166,9 @@ def test_walk_compaction_and_blend_kernels_use_no_scratch(tmp_path):
     text = out.read_text()
     kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
     seen = {frag: [k for k in kernels if frag in k[0]] for frag in ("k_pairs_scan_boxes", "k_compact", "k_blend_bwd", "k_blend_fwd", "k_sort_scatter2")}
-    assert len(seen["k_pairs_scan_boxes"]) == 12 and len(seen["k_compact"]) == 4 and all(seen.values())
+    # the walk: 3 modes x 2 address forms x 3 outputs (inclusive, inclusive + zero counts, final values + keep mask);
+    # k_compact<VEC, WRITE> x 4 and k_compact_kept<VEC> x 2
+    assert len(seen["k_pairs_scan_boxes"]) == 18 and len(seen["k_compact"]) == 6 and all(seen.values())
     bad = [(k, scratch, spills) for k, scratch, _, spills in kernels if int(scratch) or int(spills)]
     assert not bad, bad
     # eight waves per SIMD need <= 64 VGPRs, six <= 80: nothing on these paths may slip under six

@@ -733,3 +733,122 @@ def test_walk_refuses_images_too_wide_for_its_24_bit_multiply(device):
         torch.cuda.synchronize()
         assert rc == want, (width, rc)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_walk_writing_final_values_equals_walk_plus_compaction(device, monkeypatch, wide):
+    """`finish_boxes` (the walk writes inclusive / self or inclusive - self and clears the mask byte of every pair whose
+    inclusive value is exactly 0) + `compact_kept` give, BIT FOR BIT, what the inclusive walk + `compact_finish` give — on
+    inputs that drop a lot (opaque layers, NaN, -0.0, sums that cancel), for every mode, on whole arrays and on
+    `cutting_number` slices (tile-aligned and not, cut short at the end and not); and when nothing drops, the walk's own
+    output is returned as it is (views, no compaction pass)."""
+    from simplegaussiansplat_tk71_amd import raster, synthetic
+
+    if wide:
+        monkeypatch.setenv("GCP_WALK_WIDE", "1")
+    sc, rects, anti, grad = synthetic.make_scene_pairs("cfg2", seed=11, device=device)
+    start, end, w, h = sc["start"], sc["end"], sc["width"], sc["height"]
+    bins = raster.bin_tiles(start, end, w, h)
+    boff = raster.box_offsets(start, end, w, h)
+    m = anti.numel()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    prod = anti.clone()
+    prod[torch.randint(0, m, (m // 50,), generator=g).to(device)] = 0.0
+    prod[torch.randint(0, m, (m // 500,), generator=g).to(device)] = float("nan")
+    prod[5 * 4096:9 * 4096] = 0.0
+    sums = torch.randint(-2, 3, (m,), generator=g).to(device).float()
+    sums[torch.randint(0, m, (m // 40,), generator=g).to(device)] = -0.0
+    for vals, mode in ((prod, 0), (sums, 1), (sums, 2)):
+        incl, dropped = raster.scan_boxes(bins, start, end, boff, vals, mode, count_dropped=True)
+        final, keep, dropped2 = raster.finish_boxes(bins, start, end, boff, vals, mode)
+        assert torch.equal(dropped, dropped2), mode
+        assert torch.equal(keep.view(torch.bool), incl != 0), mode
+        want_final = incl / vals if mode == 0 else incl - vals
+        kept = keep.view(torch.bool)
+        assert torch.equal(final[kept].view(torch.int32), want_final[kept].view(torch.int32)), mode
+        cmode = 0 if mode == 0 else 1
+        for begin, stop in ((0, m), (0, m - 12345), (8192, m), (4096 * 7, m - 1), (777, m), (4096 * 3, 4096 * 40), (5, 5)):
+            v0, k0 = raster.compact_finish(incl, vals, cmode, begin, stop)
+            for dr in (dropped2, None):
+                v1, k1 = raster.compact_kept(final, keep, dr, begin, stop)
+                assert torch.equal(k0, k1) and v0.numel() == v1.numel(), (mode, begin, stop)
+                assert torch.equal(v0.view(torch.int32), v1.view(torch.int32)), (mode, begin, stop)
+    # nothing dropped: the walk's output is the result
+    for vals, mode in ((anti, 0), (anti, 1), (anti.abs() + 1.0, 2)):
+        final, keep, dropped = raster.finish_boxes(bins, start, end, boff, vals, mode)
+        assert int(dropped.sum()) == 0 and bool(keep.all())
+        v, k = raster.compact_kept(final, keep, dropped)
+        assert v.data_ptr() == final.data_ptr() and k.data_ptr() == keep.data_ptr() and v.numel() == m and bool(k.all())
+        v, k = raster.compact_kept(final, keep, dropped, 1001, m)
+        assert v.data_ptr() == final.data_ptr() + 4 * 1001 and v.numel() == m - 1001 and k.numel() == m - 1001
+        incl = raster.scan_boxes(bins, start, end, boff, vals, mode)
+        v0, k0 = raster.compact_finish(incl, vals, 0 if mode == 0 else 1)
+        assert torch.equal(v0.view(torch.int32), final.view(torch.int32)) and torch.equal(k0, keep.view(torch.bool))
+
+
+@pytest.mark.parametrize("n_gauss,w,h,mh,seed", [(40, 33, 17, 4, 2), (3000, 300, 200, 12, 4), (20000, 640, 426, 10, 5), (20000, 1919, 1079, 40, 6)])
+def test_one_call_cut_equals_the_step_by_step_cut_and_the_binning_count(device, n_gauss, w, h, mh, seed):
+    """gcp_rects_cut — rows, rectangles, boxes and the binning's counting pass with every count handed on in device memory
+    and ONE read at the end — against the step-by-step cut (three reads) and `bin_tiles`' own count: the same boxes, offsets,
+    image size and tile lists, int32 and int64 lists alike; and it is the route `rects_to_boxes` takes by default."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(n_gauss, w, h, mh, seed)
+    rects, _ = _rects_of(sc, device)
+    m = rects.size(0)
+    steps = raster.rects_to_boxes(rects, one_call=False)
+    assert steps is not None and steps.tile_off is None
+    for lst in (rects, rects.long()):
+        once = raster._cut_rects_once(lst.contiguous(), lst.dtype == torch.int64, 0, 0, 8)
+        if mh <= 4:  # rows of 9 pixels at most, rectangles of < 64 pairs: more than the one-call cut makes room for
+            assert once == "retry" or isinstance(once, raster.RectBoxes)
+            if once == "retry":
+                continue
+        assert isinstance(once, raster.RectBoxes), once
+        assert torch.equal(once.start, steps.start) and torch.equal(once.end, steps.end) and torch.equal(once.box_off, steps.box_off)
+        assert (once.width, once.height) == (steps.width, steps.height) and int(once.box_off[-1]) == m
+        ref_bins = raster.bin_tiles(steps.start, steps.end, steps.width, steps.height)
+        assert once.n_tile_pairs == ref_bins.n_tile_pairs
+        assert torch.equal(once.tile_off, ref_bins.tile_off)
+        bins = once.bin()
+        assert torch.equal(bins.tile_start, ref_bins.tile_start) and torch.equal(bins.tile_list, ref_bins.tile_list)
+    auto = raster.rects_to_boxes(rects)
+    assert torch.equal(auto.start, steps.start) and torch.equal(auto.box_off, steps.box_off)
+
+
+def test_one_call_cut_with_carry_rows_and_on_lists_it_has_no_room_for(device):
+    """The carry rows of a chunked call — all pixels of the image as single rows, in front (gs_model.py:611) or at the end
+    (:636) — get one slot per element and come out as one-pixel-wide columns, as in the step-by-step cut; a list of tiny
+    boxes or of unrelated coordinates is handed back ("retry": the step-by-step cut decides), x >= 10000 is refused."""
+    from simplegaussiansplat_tk71_amd import raster
+
+    sc = make_scene(4000, 300, 200, 14, 9)
+    rects, _ = _rects_of(sc, device)
+    w, h = sc["width"], sc["height"]
+    xs = torch.arange(w + 1, device=device, dtype=torch.int32)
+    ys = torch.arange(h + 1, device=device, dtype=torch.int32)
+    carry = torch.stack([xs[:, None].expand(-1, h + 1).reshape(-1), ys[None, :].expand(w + 1, -1).reshape(-1)], 1)  # torch.unique's order
+    c = carry.size(0)
+    for at_end in (False, True):
+        lst = torch.cat([rects, carry] if at_end else [carry, rects]).contiguous()
+        steps = raster.rects_to_boxes(lst, carry_rows=c, carry_at_end=at_end, one_call=False)
+        once = raster._cut_rects_once(lst, False, 0 if at_end else c, c if at_end else 0, 8)
+        assert isinstance(once, raster.RectBoxes), once
+        assert torch.equal(once.start, steps.start) and torch.equal(once.end, steps.end) and torch.equal(once.box_off, steps.box_off)
+        # without being told about the carry rows their tiles overflow the 512 slots: handed back, not mis-cut
+        assert raster._cut_rects_once(lst, False, 0, 0, 8) == "retry"
+        assert raster.rects_to_boxes(lst, carry_rows=c, carry_at_end=at_end) is not None
+    g = torch.Generator().manual_seed(3)
+    n = 60_000
+    rnd = torch.stack([torch.randint(0, 200, (n,), generator=g), torch.randint(0, 150, (n,), generator=g)], 1).to(torch.int32).to(device)
+    assert raster._cut_rects_once(rnd, False, 0, 0, 8) == "retry" and raster.rects_to_boxes(rnd) is None
+    tiny = make_scene(5000, 300, 200, 1, 4)   # boxes of 3 x 3 pixels at most
+    trects, _ = _rects_of(tiny, device)
+    assert raster._cut_rects_once(trects, False, 0, 0, 8) == "retry"
+    far = rects.clone()
+    far[:, 0] += 9990
+    assert raster._cut_rects_once(far, False, 0, 0, 8) is None
+    neg = rects.clone()
+    neg[17, 1] = -4
+    with pytest.raises(RuntimeError, match="negative"):
+        raster._cut_rects_once(neg, False, 0, 0, 8)

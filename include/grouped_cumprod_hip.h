@@ -354,9 +354,9 @@ int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t 
  * of boxes yields about as many rectangles as elements, and the caller then sorts instead.
  *   gcp_rects_rows: rows = maximal runs (x, y), (x+1, y), ...  row_start[k] = index of the k-th row's first element,
  *     row_start[rows] = n, row_xy[k] = its (x, y); both have room for row_capacity entries.  info (device int32[5]) =
- *     {rows, max x, max y, min coordinate, not_boxes}; not_boxes = 1: the list has more than row_capacity - 1 rows, or an
- *     x >= 10000 (the reference's key y * 10000 + x then merges different pixels, gs_model.py:538-541: only the key-based
- *     sort route reproduces its groups) or a y >= 2^17 — nothing was written, sort instead.  gcp_rects_rows_capacity(n) = n / 2 + 2
+ *     {rows, max x, max y, min coordinate, not_boxes}; not_boxes != 0 — bit 1: the list has more than row_capacity - 1 rows;
+ *     bit 0: an x >= 10000 (the reference's key y * 10000 + x then merges different pixels, gs_model.py:538-541: only the
+ *     key-based sort route reproduces its groups) or a y >= 2^17 — nothing was written, sort instead.  gcp_rects_rows_capacity(n) = n / 2 + 2
  *     is what a list of boxes is allowed; a caller whose list starts or ends with c single-pixel carry rows (the
  *     `cutting_number` rows of gs_model.py:611, :636 — lexicographically sorted unique pixels: they come out as one-pixel-wide
  *     rectangles) passes c + gcp_rects_rows_capacity(n - c).
@@ -375,14 +375,16 @@ int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t 
  *     sums of the tiles every rectangle touches, tile_off[rectangles] = K — the image being [0, max x] x [0, max y], the
  *     binning's clamp is the identity) are valid: hand them to gcp_bin_tiles_fill(…, max x, max y, tile_off, K, …).
  *     1 = a coordinate the walk cannot take (x >= 10000, y >= 2^17: see gcp_rects_rows) — sort instead;
- *     2 = a 4096-pair tile holds more than slot_rows rows — repeat with more slots (gcp_rects_rows: 4096) or sort;
+ *     2 = more rows than there is room for (slot_rows per 4096-pair tile on average; tiles that need more draw on a shared
+ *       pool of n / 32 records) — take the step-by-step cut (gcp_rects_rows: room for a row per two pairs) or sort;
  *     4 = more than rect_capacity rectangles; 8 = K does not fit int32.  A negative min coordinate: refuse the list.
  *   slot_rows: row records a tile of boxes may park (<= 4096; 512 serves boxes of 8 columns and more).  carry_front /
  *     carry_back: the list starts / ends with that many single-pixel carry rows (the `cutting_number` rows of gs_model.py:611,
  *     :636): their tiles get one slot per element.  rect_capacity: rectangles start_xy / end_xy (int32[cap][2]), box_off and
  *     tile_off (int32[cap + 1]) have room for.
- * Scratch (ws, 256-byte aligned): 8 B x slot_rows per tile + 12 B per row slot + a few words per tile: 2.5 B per pair at
- * slot_rows = 512, against gcp_rects_rows' 8 B + the caller's 6 B per pair. */
+ * Scratch (ws, 256-byte aligned): 8 B x slot_rows per tile for the parked records, as much again for the rows (kept
+ * packed), the pool and a few words per tile: 2.3 B per pair at slot_rows = 512 (+ 28 B per rectangle of capacity in the
+ * caller's arrays: 0.45 B per pair at 64 pairs per rectangle), against gcp_rects_rows' 8 B + the caller's 6 B per pair. */
 size_t gcp_rects_cut_workspace_bytes(int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows, int64_t rect_capacity);
 int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows,
                   int64_t rect_capacity, int32_t* start_xy, int32_t* end_xy, int32_t* box_off, int32_t* tile_off, int32_t* info8,

@@ -42,9 +42,14 @@ constexpr int kRowTile = 1024;                    // rows per block in the secon
 // list "not boxes at this capacity" and the caller repeats with more or sorts); only the tiles that hold the single-pixel
 // carry rows of a chunked call — [0, front_tiles) when they lead the list (gs_model.py:611), [back_tile0, n_tiles) when
 // they trail it (:636) — get one slot per element.  0 <= front_tiles <= back_tile0 <= n_tiles.
+// A tile that needs more than its slots (a stretch of narrow boxes in a list of wide ones) parks the excess in a POOL shared
+// by all tiles: one atomic add on the pool's fill per overflowing tile reserves its run there (pool_off[tile]); where the
+// records lie does not matter — the second pass moves them to places that depend on the counts alone — so the result stays
+// deterministic.  Only when the pool runs out too is the list handed back (kNotBoxesSlots).
 struct SlotLayout {
   i64 front_tiles, back_tile0;
   int slot_rows;
+  i64 pool_rows;  // capacity of the shared pool, in records (0: none)
   __host__ __device__ i64 base(i64 t) const {
     const i64 a = t < front_tiles ? t : front_tiles;
     const i64 m = (t < back_tile0 ? t : back_tile0) - front_tiles;
@@ -54,9 +59,10 @@ struct SlotLayout {
   __host__ __device__ int cap(i64 t) const { return (t < front_tiles || t >= back_tile0) ? kSlotRowsMax : slot_rows; }
 };
 
-inline SlotLayout slot_layout(i64 n, i64 carry_front, i64 carry_back, int slot_rows) {
+inline SlotLayout slot_layout(i64 n, i64 carry_front, i64 carry_back, int slot_rows, i64 pool_rows = 0) {
   const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
   SlotLayout L;
+  L.pool_rows = pool_rows > 0 ? pool_rows : 0;
   L.slot_rows = slot_rows < 1 ? 1 : (slot_rows > kSlotRowsMax ? kSlotRowsMax : slot_rows);
   carry_front = carry_front < 0 ? 0 : (carry_front > n ? n : carry_front);
   carry_back = carry_back < 0 ? 0 : (carry_back > n ? n : carry_back);
@@ -69,8 +75,8 @@ inline SlotLayout slot_layout(i64 n, i64 carry_front, i64 carry_back, int slot_r
 }
 
 // info[4] of the first cut: why the list cannot be walked as boxes
-constexpr int kNotBoxesRange = 1;     // a coordinate the walk cannot take (x >= 10000: the reference's key merges pixels; y >= 2^17), or more rows than the caller made room for
-constexpr int kNotBoxesSlots = 2;     // a tile parked more row records than its slots hold: repeat with more slots per tile, or sort
+constexpr int kNotBoxesRange = 1;     // a coordinate the walk cannot take (x >= 10000: the reference's key merges pixels; y >= 2^17)
+constexpr int kNotBoxesSlots = 2;     // more rows than there is room for — in a tile's slots and the pool, or in the caller's row arrays
 
 // Ranks of the set bits of m[0..ROWS) inside the block: thread t of wave w holds the flags of the 4 consecutive items
 // w * 256 * ROWS + r * 256 + lane * 4 + k.  rank[r] = flags in front of the thread's row r; returns the block's count.
@@ -113,8 +119,11 @@ __device__ __forceinline__ int2 rect_at(const void* __restrict__ rects, i64 i) {
 template <bool I64>
 __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, const SlotLayout L,
                                                          int2* __restrict__ slots /*tile t: [L.base(t), + L.cap(t)): {index, x | y << 14}*/,
-                                                         int* __restrict__ cnt, int* __restrict__ info /*[5]: rows, max x, max y, min, not-boxes flags*/) {
+                                                         int2* __restrict__ pool, unsigned long long* __restrict__ pool_fill,
+                                                         int* __restrict__ pool_off /*[tiles]*/, int* __restrict__ cnt,
+                                                         int* __restrict__ info /*[5]: rows, max x, max y, min, not-boxes flags*/) {
   __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
+  __shared__ long long s_pool;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 tile = blockIdx.x;
   const i64 base = tile * kElemTile + (i64)w * (256 * kRowsPerThread);
@@ -177,7 +186,24 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   int rank[kRowsPerThread];
   const int count = block_ranks<kRowsPerThread>(m, rank, s_w);
   int2* const mine = slots + L.base(tile);
-  const bool fits = count <= L.cap(tile);  // block-uniform
+  const int cap = L.cap(tile);
+  bool fits = count <= cap;  // block-uniform
+  int2* extra = nullptr;     // where the records beyond the tile's own slots go
+  if (!fits && L.pool_rows > 0) {
+    if (threadIdx.x == 0) {
+      // (look before the atomic: a list that is not made of boxes overflows in EVERY tile, and the pool is full after the
+      // first few hundred of them)
+      long long at = -1;
+      if (__hip_atomic_load(pool_fill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)L.pool_rows) {
+        at = (long long)atomicAdd(pool_fill, (unsigned long long)(count - cap));
+        if (at + (count - cap) > L.pool_rows) at = -1;
+      }
+      s_pool = at;
+      if (at >= 0) pool_off[tile] = (int)at;
+    }
+    __syncthreads();
+    if (s_pool >= 0) { fits = true; extra = pool + s_pool; }
+  }
   if (fits) {
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
@@ -186,7 +212,9 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if ((m[r] >> k) & 1u) {
-          mine[o] = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+          const int2 rec = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+          if (o < cap) mine[o] = rec;
+          else extra[o - cap] = rec;
           ++o;
         }
       }
@@ -216,28 +244,49 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   }
 }
 
+// The rows of the first cut as the later stages read them: split — the public form, row_start int[rows + 1] (+ sentinel n)
+// and row_xy int2[rows] — or packed, the one-call cut's scratch form: the 8-byte slot records as they are,
+// {first element, x | y << 14}, and a sentinel record {n, 0}: 8 B per row instead of 12.
+struct Rows {
+  const int* start;
+  const int2* xy;
+  const int2* packed;
+  __device__ __forceinline__ int first(i64 r) const { return packed ? packed[r].x : start[r]; }
+  __device__ __forceinline__ int2 at(i64 r) const {
+    if (!packed) return xy[r];
+    const int q = packed[r].y;
+    return make_int2(q & 0x3fff, (int)((unsigned)q >> 14));
+  }
+};
+
 // ---- cut 1, pass 2: the parked records to their final places -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const SlotLayout L, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
+__global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict__ slots, const SlotLayout L, const int2* __restrict__ pool,
+                                                          const int* __restrict__ pool_off, const int* __restrict__ off /*[tiles + 1]*/, i64 n,
                                                           i64 n_tiles, i64 row_capacity, int* __restrict__ row_start,
-                                                          int2* __restrict__ row_xy, int* __restrict__ info) {
+                                                          int2* __restrict__ row_xy, int2* __restrict__ row_packed /*or: the packed form*/,
+                                                          int* __restrict__ info) {
   const i64 tile = blockIdx.x;
   const int flags = info[4];  // written by the launch before this one
   if (flags != 0 || (i64)off[n_tiles] + 1 > row_capacity) {
     // not a list the walk can take (coordinates, a tile with more rows than slots) or more rows than the caller made room
     // for: nothing is written
-    if (tile == 0 && threadIdx.x == 0) { info[0] = off[n_tiles]; if (flags == 0) info[4] = kNotBoxesRange; }
+    if (tile == 0 && threadIdx.x == 0) { info[0] = off[n_tiles]; if (flags == 0) info[4] = kNotBoxesSlots; }
     return;
   }
   const int o0 = off[tile], c = off[tile + 1] - o0;
   const int2* const mine = slots + L.base(tile);
+  const int cap = L.cap(tile);
+  const int2* const extra = c > cap ? pool + pool_off[tile] : nullptr;
   for (int i = threadIdx.x; i < c; i += 256) {
-    const int2 q = mine[i];
+    const int2 q = i < cap ? mine[i] : extra[i - cap];
+    if (row_packed) { row_packed[o0 + i] = q; continue; }
     row_start[o0 + i] = q.x;
     row_xy[o0 + i] = make_int2(q.y & 0x3fff, (int)((unsigned)q.y >> 14));
   }
   if (tile == n_tiles - 1 && threadIdx.x == 0) {
     info[0] = off[n_tiles];
-    row_start[off[n_tiles]] = (int)n;  // sentinel: the end of the last row
+    if (row_packed) row_packed[off[n_tiles]] = make_int2((int)n, 0);
+    else row_start[off[n_tiles]] = (int)n;  // sentinel: the end of the last row
   }
 }
 
@@ -245,7 +294,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict
 // rows_dev: NULL (n_rows is the host's count), or the first cut's info on the device — the grid then covers the row
 // CAPACITY, the count is info[0], and a list the first cut refused (info[4] != 0) has no rows at all.
 template <bool WRITE>
-__global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__ row_start, const int2* __restrict__ row_xy, i64 n_rows,
+__global__ __launch_bounds__(256) void k_rows_rectangles(const Rows rows, i64 n_rows,
                                                          const int* __restrict__ rows_dev, int* __restrict__ cnt, const int* __restrict__ off,
                                                          int* __restrict__ rect_row, int* __restrict__ info) {
   __shared__ int s_w[4];
@@ -256,12 +305,12 @@ __global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__
   unsigned m[1] = {0u};
   // rows p-1 .. p+3: first x, y and length (row_start has n_rows + 1 entries)
   int x0 = 0, y0 = 0, len0 = -1;
-  if (p > 0 && p <= n_rows) { const int2 q = row_xy[p - 1]; x0 = q.x; y0 = q.y; len0 = row_start[p] - row_start[p - 1]; }
+  if (p > 0 && p <= n_rows) { const int2 q = rows.at(p - 1); x0 = q.x; y0 = q.y; len0 = rows.first(p) - rows.first(p - 1); }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (p + k < n_rows) {
-      const int2 q = row_xy[p + k];
-      const int len = row_start[p + k + 1] - row_start[p + k];
+      const int2 q = rows.at(p + k);
+      const int len = rows.first(p + k + 1) - rows.first(p + k);
       const bool cont = len0 >= 0 && q.x == x0 && len == len0 && q.y == y0 + 1;
       m[0] |= (cont ? 0u : 1u) << k;
       x0 = q.x; y0 = q.y; len0 = len;
@@ -288,8 +337,8 @@ __global__ __launch_bounds__(256) void k_rows_rectangles(const int* __restrict__
 // entries and the count is rects_dev[0].  tile_cnt (with rects_dev): the number of 16x16 tiles every rectangle touches —
 // the boxes lie inside [0, max x] x [0, max y] by construction, so the binning's clamp is the identity and its counting
 // pass (gcp_bin_tiles_count) is this line — zeros behind the last rectangle, and their 64-bit total.
-__global__ __launch_bounds__(256) void k_rectangle_boxes(const int* __restrict__ rect_row, const int* __restrict__ row_start,
-                                                         const int2* __restrict__ row_xy, i64 n_rects, i64 n, const int* __restrict__ rects_dev,
+__global__ __launch_bounds__(256) void k_rectangle_boxes(const int* __restrict__ rect_row, const Rows rows, i64 n_rects, i64 n,
+                                                         const int* __restrict__ rects_dev,
                                                          i64 capacity, int* __restrict__ start_xy, int* __restrict__ end_xy,
                                                          int* __restrict__ box_off, int* __restrict__ tile_cnt,
                                                          unsigned long long* __restrict__ total64) {
@@ -307,14 +356,15 @@ __global__ __launch_bounds__(256) void k_rectangle_boxes(const int* __restrict__
     int c = 0;
     if (fits && b < n_rects) {
       const int r0 = rect_row[b], r1 = rect_row[b + 1];
-      const int2 q = row_xy[r0];
-      const int len = row_start[r0 + 1] - row_start[r0];
+      const int2 q = rows.at(r0);
+      const int f0 = rows.first(r0);
+      const int len = rows.first(r0 + 1) - f0;
       const int x1 = q.x + len - 1, y1 = q.y + (r1 - r0) - 1;
       start_xy[2 * b] = q.x;
       start_xy[2 * b + 1] = q.y;
       end_xy[2 * b] = x1;
       end_xy[2 * b + 1] = y1;
-      box_off[b] = row_start[r0];
+      box_off[b] = f0;
       c = ((x1 >> 4) - (q.x >> 4) + 1) * ((y1 >> 4) - (q.y >> 4) + 1);
     } else if (fits && b == n_rects) {
       box_off[b] = (int)n;
@@ -353,7 +403,8 @@ extern "C" {
 
 static size_t rows_ws_bytes(i64 n, const SlotLayout& L) {
   const i64 t = (n > 0 ? n + kElemTile - 1 : kElemTile) / kElemTile;
-  return align256((size_t)(L.base(t) + 1) * sizeof(int2)) + 2 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
+  return align256((size_t)(L.base(t) + 1) * sizeof(int2)) + align256((size_t)(L.pool_rows + 1) * sizeof(int2)) + 256 +
+         3 * align256((size_t)(t + 1) * sizeof(int)) + gcp_scan_i32_workspace_bytes(t);
 }
 
 // every tile with one slot per element: a list of anything, 8 B of scratch per element
@@ -361,27 +412,34 @@ size_t gcp_rects_rows_workspace_bytes(int64_t n) { return rows_ws_bytes(n, slot_
 
 // the first cut; `slots_out` (optional) receives the slot region's address — dead once this call's launches are through
 static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, const SlotLayout& L, int64_t row_capacity, int32_t* row_start,
-                           int32_t* row_xy, int32_t* info, void* ws, size_t ws_bytes, void* stream_, void** slots_out = nullptr) {
+                           int32_t* row_xy, int32_t* info, void* ws, size_t ws_bytes, void* stream_, void** slots_out = nullptr,
+                           int2* row_packed = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || n > 0x7fffffffLL || row_capacity < 1 || !info) return GCP_ERR_INVALID_ARGUMENT;
   GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), not-boxes flags
   GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info + 3), 0x7fffffff, 1, stream));   // min coordinate
   if (n == 0) return GCP_OK;
-  if (!rects_xy || !row_start || !row_xy || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if (!rects_xy || (!row_packed && (!row_start || !row_xy)) || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n_tiles = (n + kElemTile - 1) / kElemTile;
   if (ws_bytes < rows_ws_bytes(n, L)) return GCP_ERR_WORKSPACE;
   char* p = (char*)ws;
   int2* slots = (int2*)p; p += align256((size_t)(L.base(n_tiles) + 1) * sizeof(int2));
+  int2* pool = (int2*)p; p += align256((size_t)(L.pool_rows + 1) * sizeof(int2));
+  unsigned long long* pool_fill = (unsigned long long*)p; p += 256;
+  int* pool_off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   if (slots_out) *slots_out = slots;
-  if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, cnt, info);
-  else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, cnt, info);
+  if (L.pool_rows > 0) GCP_HIP(hipMemsetAsync(pool_fill, 0, sizeof(unsigned long long), stream));
+  if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, pool, pool_fill,
+                               pool_off, cnt, info);
+  else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, pool, pool_fill,
+                          pool_off, cnt, info);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, L, (const int*)off, (i64)n, n_tiles,
-                     (i64)row_capacity, row_start, (int2*)row_xy, info);
+  hipLaunchKernelGGL(k_rect_rows_gather, dim3((unsigned)n_tiles), dim3(256), 0, stream, (const int2*)slots, L, (const int2*)pool,
+                     (const int*)pool_off, (const int*)off, (i64)n, n_tiles, (i64)row_capacity, row_start, (int2*)row_xy, row_packed, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
@@ -407,24 +465,24 @@ size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows) {
 }
 
 // n_rows: the row count, or — with rows_dev, the first cut's info on the device — the row CAPACITY the grid has to cover
-static int rows_rectangles_impl(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, const int* rows_dev, int32_t* rect_row,
+static int rows_rectangles_impl(const Rows rows, int64_t n_rows, const int* rows_dev, int32_t* rect_row,
                                 int32_t* info, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || n_rows > 0x7fffffffLL || !info) return GCP_ERR_INVALID_ARGUMENT;
   GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));  // rectangles, (unused)
   if (n_rows == 0) return GCP_OK;
-  if (!row_start || !row_xy || !rect_row || !ws) return GCP_ERR_INVALID_ARGUMENT;
+  if ((!rows.packed && (!rows.start || !rows.xy)) || !rect_row || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n_tiles = (n_rows + kRowTile - 1) / kRowTile;
   if (ws_bytes < gcp_rows_rectangles_workspace_bytes(n_rows)) return GCP_ERR_WORKSPACE;
   char* p = (char*)ws;
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
-  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, rows_dev,
+  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
                      cnt, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, row_start, (const int2*)row_xy, (i64)n_rows, rows_dev,
+  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
                      (int*)nullptr, (const int*)off, rect_row, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
@@ -432,7 +490,7 @@ static int rows_rectangles_impl(const int32_t* row_start, const int32_t* row_xy,
 
 int gcp_rows_rectangles(const int32_t* row_start, const int32_t* row_xy, int64_t n_rows, int32_t* rect_row, int32_t* info, void* ws,
                         size_t ws_bytes, void* stream) {
-  return rows_rectangles_impl(row_start, row_xy, n_rows, nullptr, rect_row, info, ws, ws_bytes, stream);
+  return rows_rectangles_impl(Rows{row_start, (const int2*)row_xy, nullptr}, n_rows, nullptr, rect_row, info, ws, ws_bytes, stream);
 }
 
 int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const int32_t* row_xy, int64_t n_rects, int64_t n,
@@ -440,9 +498,9 @@ int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rects < 0 || n < 0 || !box_off) return GCP_ERR_INVALID_ARGUMENT;
   if (n_rects > 0 && (!rect_row || !row_start || !row_xy || !start_xy || !end_xy)) return GCP_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)((n_rects + 1 + 255) / 256)), dim3(256), 0, stream, rect_row, row_start, (const int2*)row_xy,
-                     (i64)n_rects, (i64)n, (const int*)nullptr, (i64)n_rects, start_xy, end_xy, box_off, (int*)nullptr,
-                     (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)((n_rects + 1 + 255) / 256)), dim3(256), 0, stream, rect_row,
+                     Rows{row_start, (const int2*)row_xy, nullptr}, (i64)n_rects, (i64)n, (const int*)nullptr, (i64)n_rects, start_xy, end_xy,
+                     box_off, (int*)nullptr, (unsigned long long*)nullptr);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
@@ -452,7 +510,11 @@ int gcp_rectangle_boxes(const int32_t* rect_row, const int32_t* row_start, const
 // info8 ONCE and knows everything the binning and the walk need.  Scratch: the slot region (8 B x slot_rows per 4096-pair
 // tile; the rectangle list of the second cut re-uses it), the rows (12 B each, at most one per slot), a few words per tile —
 // with 512 slots per tile 2.5 B per pair, plus 28 B per rectangle of capacity in the caller's arrays.
+// rows the one-call cut makes room for: as many as it has slots (an eighth of the list at 512 per tile, + the carry rows) —
+// the pool only evens out between tiles
 static i64 cut_row_capacity(i64 n, const SlotLayout& L) { return L.base((n + kElemTile - 1) / kElemTile) + 1; }
+// the pool of the one-call cut: a thirty-second of the list (0.25 B per pair) for the tiles that exceed their slots
+static i64 cut_pool_rows(i64 n) { return n / 32 + 1024; }
 
 struct CutWs {
   size_t rows_ws, row_start, row_xy, rect_ws, tile_cnt, scan_ws, info, total;
@@ -462,8 +524,8 @@ static CutWs cut_ws_layout(i64 n, const SlotLayout& L, i64 rect_capacity) {
   CutWs w;
   size_t o = 0;
   w.rows_ws = o; o += align256(rows_ws_bytes(n, L));
-  w.row_start = o; o += align256((size_t)(rc + 1) * sizeof(int));
-  w.row_xy = o; o += align256((size_t)rc * sizeof(int2));
+  w.row_start = o;                                              // (unused: the rows stay packed)
+  w.row_xy = o; o += align256((size_t)(rc + 1) * sizeof(int2));  // packed rows + sentinel
   w.rect_ws = o; o += align256(gcp_rows_rectangles_workspace_bytes(rc));
   w.tile_cnt = o; o += align256((size_t)(rect_capacity + 1) * sizeof(int));
   w.scan_ws = o; o += align256(gcp_scan_i32_workspace_bytes(rect_capacity + 1));
@@ -474,7 +536,7 @@ static CutWs cut_ws_layout(i64 n, const SlotLayout& L, i64 rect_capacity) {
 
 size_t gcp_rects_cut_workspace_bytes(int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows, int64_t rect_capacity) {
   if (n < 0 || rect_capacity < 0) return 0;
-  return cut_ws_layout(n, slot_layout(n, carry_front, carry_back, slot_rows), rect_capacity).total + 256;
+  return cut_ws_layout(n, slot_layout(n, carry_front, carry_back, slot_rows, cut_pool_rows(n)), rect_capacity).total + 256;
 }
 
 int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows,
@@ -490,30 +552,30 @@ int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int6
     return GCP_OK;
   }
   if (!rects_xy || !start_xy || !end_xy || !box_off || !tile_off || !ws) return GCP_ERR_INVALID_ARGUMENT;
-  const SlotLayout L = slot_layout(n, carry_front, carry_back, slot_rows);
+  const SlotLayout L = slot_layout(n, carry_front, carry_back, slot_rows, cut_pool_rows(n));
   const CutWs w = cut_ws_layout(n, L, rect_capacity);
   if (ws_bytes < w.total + 256 || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
   char* const base = (char*)ws;
-  int* const row_start = (int*)(base + w.row_start);
-  int* const row_xy = (int*)(base + w.row_xy);
+  int2* const row_packed = (int2*)(base + w.row_xy);
+  const Rows rows{nullptr, nullptr, row_packed};
   int* const info_rows = (int*)(base + w.info);
   int* const info_rects = info_rows + 8;
   unsigned long long* const total64 = (unsigned long long*)(base + w.total);
   int* const tile_cnt = (int*)(base + w.tile_cnt);
   const i64 row_cap = cut_row_capacity(n, L);
   void* slots = nullptr;
-  int st = rects_rows_impl(rects_xy, rects_are_int64 != 0, n, L, row_cap, row_start, row_xy, info_rows, base + w.rows_ws, rows_ws_bytes(n, L), stream_, &slots);
+  int st = rects_rows_impl(rects_xy, rects_are_int64 != 0, n, L, row_cap, nullptr, nullptr, info_rows, base + w.rows_ws, rows_ws_bytes(n, L), stream_, &slots,
+                           row_packed);
   if (st != GCP_OK) return st;
   // the rectangle list (one int per rectangle, at most one per row, + the sentinel) re-uses the slot region: its records
   // have all been moved to the rows by now (8 B per slot there, 4 B per row here)
   int* const rect_row = (int*)slots;
-  st = rows_rectangles_impl(row_start, row_xy, row_cap, info_rows, rect_row, info_rects, base + w.rect_ws, gcp_rows_rectangles_workspace_bytes(row_cap), stream_);
+  st = rows_rectangles_impl(rows, row_cap, info_rows, rect_row, info_rects, base + w.rect_ws, gcp_rows_rectangles_workspace_bytes(row_cap), stream_);
   if (st != GCP_OK) return st;
   GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
   const i64 box_blocks = (rect_capacity + 1 + 255) / 256 < 1024 ? (rect_capacity + 1 + 255) / 256 : 1024;
-  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)box_blocks), dim3(256), 0, stream, (const int*)rect_row,
-                     (const int*)row_start, (const int2*)row_xy, (i64)0, (i64)n, (const int*)info_rects, (i64)rect_capacity, start_xy, end_xy,
-                     box_off, tile_cnt, total64);
+  hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)box_blocks), dim3(256), 0, stream, (const int*)rect_row, rows, (i64)0, (i64)n,
+                     (const int*)info_rects, (i64)rect_capacity, start_xy, end_xy, box_off, tile_cnt, total64);
   GCP_HIP(hipGetLastError());
   st = gcp_exclusive_scan_i32(tile_cnt, tile_off, rect_capacity, base + w.scan_ws, gcp_scan_i32_workspace_bytes(rect_capacity + 1), stream_);
   if (st != GCP_OK) return st;

@@ -35,7 +35,7 @@ constexpr int kRowsPerThread = 4;                 // 16 elements per thread
 constexpr int kElemTile = 1024 * kRowsPerThread;  // 4096 elements per block
 constexpr int kSlotRowsMax = kElemTile;           // row records a tile may park at most: every element may start a row (the carry rows
                                                   // of a chunked call, gs_model.py:611, are single pixels)
-constexpr int kRowTile = 1024;                    // rows per block in the second cut, 4 per thread
+constexpr int kRowTile = 1024 * kRowsPerThread;   // rows per block in the second cut, 16 per thread
 
 // Where tile t parks its row records.  A list of boxes parks ~ 4096 / (box width) records per tile, so the tiles of the
 // boxes get `slot_rows` slots each (512 by default: 1 B of scratch per pair instead of 8; a tile that needs more marks the
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_gather(const int2* __restrict
 // ---- cut 2: rows -> rectangles (count, then write) -------------------------------------------------------------------------
 // rows_dev: NULL (n_rows is the host's count), or the first cut's info on the device — the grid then covers the row
 // CAPACITY, the count is info[0], and a list the first cut refused (info[4] != 0) has no rows at all.
-template <bool WRITE>
+template <bool WRITE, bool PACKED>
 __global__ __launch_bounds__(256) void k_rows_rectangles(const Rows rows, i64 n_rows,
                                                          const int* __restrict__ rows_dev, int* __restrict__ cnt, const int* __restrict__ off,
                                                          int* __restrict__ rect_row, int* __restrict__ info) {
@@ -301,34 +301,65 @@ __global__ __launch_bounds__(256) void k_rows_rectangles(const Rows rows, i64 n_
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 tile = blockIdx.x;
   if (rows_dev) n_rows = rows_dev[4] ? 0 : (i64)rows_dev[0];
-  const i64 p = tile * kRowTile + (i64)w * 256 + lane * 4;
-  unsigned m[1] = {0u};
-  // rows p-1 .. p+3: first x, y and length (row_start has n_rows + 1 entries)
-  int x0 = 0, y0 = 0, len0 = -1;
-  if (p > 0 && p <= n_rows) { const int2 q = rows.at(p - 1); x0 = q.x; y0 = q.y; len0 = rows.first(p) - rows.first(p - 1); }
+  if (tile * kRowTile >= n_rows && !(tile == 0)) {  // a block of the capacity grid behind the last row: nothing to find
+    if (!WRITE && threadIdx.x == 0) cnt[tile] = 0;
+    return;
+  }
+  // 16 rows per thread as four groups of four consecutive ones (the item order of block_ranks): of rows p - 1 .. p + 4 the
+  // first element, and of p - 1 .. p + 3 the first pixel — all loads of the thread are issued before the first compare
+  const i64 base = tile * kRowTile + (i64)w * (256 * kRowsPerThread);
+  int3 q[kRowsPerThread][6];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (p + k < n_rows) {
-      const int2 q = rows.at(p + k);
-      const int len = rows.first(p + k + 1) - rows.first(p + k);
-      const bool cont = len0 >= 0 && q.x == x0 && len == len0 && q.y == y0 + 1;
-      m[0] |= (cont ? 0u : 1u) << k;
-      x0 = q.x; y0 = q.y; len0 = len;
+  for (int r = 0; r < kRowsPerThread; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      // straight-line loads (a load behind a branch makes every later one wait for it, the lesson of the walk): an index
+      // outside the rows is clamped to one inside, its value never used
+      i64 j = p - 1 + k;
+      j = j < 0 ? 0 : (j > n_rows ? n_rows : j);
+      if (PACKED) {
+        const int2 v = rows.packed[j];  // (the sentinel {n, 0} sits at n_rows)
+        q[r][k] = make_int3(v.x, v.y & 0x3fff, (int)((unsigned)v.y >> 14));
+      } else {
+        const int2 xy = rows.xy[j < n_rows ? j : (n_rows > 0 ? n_rows - 1 : 0)];
+        q[r][k] = make_int3(rows.start[j], xy.x, xy.y);
+      }
     }
   }
-  int rank[1];
-  const int count = block_ranks<1>(m, rank, s_w);
+  unsigned m[kRowsPerThread];
+#pragma unroll
+  for (int r = 0; r < kRowsPerThread; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    m[r] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p + k < n_rows) {
+        // row p + k continues the rectangle of the row in front of it: same first column, same length, the next line
+        const bool cont = p + k > 0 && q[r][k + 1].y == q[r][k].y && q[r][k + 2].x - q[r][k + 1].x == q[r][k + 1].x - q[r][k].x &&
+                          q[r][k + 1].z == q[r][k].z + 1;
+        m[r] |= (cont ? 0u : 1u) << k;
+      }
+    }
+  }
+  int rank[kRowsPerThread];
+  const int count = block_ranks<kRowsPerThread>(m, rank, s_w);
   if (!WRITE) {
     if (threadIdx.x == 0) cnt[tile] = count;
     return;
   }
-  int o = off[tile] + rank[0];
+  const int o0 = off[tile];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if ((m[0] >> k) & 1u) rect_row[o++] = (int)(p + k);  // (as many rectangles as rows at most: the caller sized it so)
+  for (int r = 0; r < kRowsPerThread; ++r) {
+    const i64 p = base + r * 256 + lane * 4;
+    int o = o0 + rank[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((m[r] >> k) & 1u) rect_row[o++] = (int)(p + k);  // (as many rectangles as rows at most: the caller sized it so)
+  }
   if (threadIdx.x == 0 && tile == (n_rows > 0 ? (n_rows - 1) / kRowTile : 0)) {  // the block that holds the last row
-    info[0] = off[tile] + count;
-    rect_row[off[tile] + count] = (int)n_rows;  // sentinel
+    info[0] = o0 + count;
+    rect_row[o0 + count] = (int)n_rows;  // sentinel
   }
 }
 
@@ -341,52 +372,60 @@ __global__ __launch_bounds__(256) void k_rectangle_boxes(const int* __restrict__
                                                          const int* __restrict__ rects_dev,
                                                          i64 capacity, int* __restrict__ start_xy, int* __restrict__ end_xy,
                                                          int* __restrict__ box_off, int* __restrict__ tile_cnt,
-                                                         unsigned long long* __restrict__ total64) {
-  __shared__ unsigned long long s_total;
-  if (tile_cnt) {
-    if (threadIdx.x == 0) s_total = 0;
-    __syncthreads();
-  }
+                                                         unsigned long long* __restrict__ block_sum /*[gridDim.x], with tile_cnt*/) {
+  __shared__ int s_w[4];
   if (rects_dev) n_rects = rects_dev[0];
   const bool fits = !rects_dev || n_rects <= capacity;  // more rectangles than the caller made room for: flagged by the finishing kernel
-  const i64 span = rects_dev ? capacity + 1 : n_rects + 1;
-  unsigned long long wide = 0;
-  // grid-stride (the fused cut launches few blocks: a few hundred atomics on the 64-bit total, not one per 256 rectangles)
-  for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b < span; b += (i64)gridDim.x * blockDim.x) {
-    int c = 0;
-    if (fits && b < n_rects) {
-      const int r0 = rect_row[b], r1 = rect_row[b + 1];
-      const int2 q = rows.at(r0);
-      const int f0 = rows.first(r0);
-      const int len = rows.first(r0 + 1) - f0;
-      const int x1 = q.x + len - 1, y1 = q.y + (r1 - r0) - 1;
-      start_xy[2 * b] = q.x;
-      start_xy[2 * b + 1] = q.y;
-      end_xy[2 * b] = x1;
-      end_xy[2 * b + 1] = y1;
-      box_off[b] = f0;
-      c = ((x1 >> 4) - (q.x >> 4) + 1) * ((y1 >> 4) - (q.y >> 4) + 1);
-    } else if (fits && b == n_rects) {
-      box_off[b] = (int)n;
+  const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = 0;
+  if (fits && b < n_rects) {
+    const int r0 = rect_row[b], r1 = rect_row[b + 1];
+    int2 q;
+    int f0, f1;
+    if (rows.packed) {  // (wave-uniform; both records with one 8-byte load each)
+      const int2 v0 = rows.packed[r0], v1 = rows.packed[r0 + 1];
+      q = make_int2(v0.y & 0x3fff, (int)((unsigned)v0.y >> 14));
+      f0 = v0.x; f1 = v1.x;
+    } else {
+      q = rows.xy[r0];
+      f0 = rows.start[r0]; f1 = rows.start[r0 + 1];
     }
-    if (tile_cnt && b < capacity) tile_cnt[b] = c;
-    wide += (unsigned long long)c;
+    const int x1 = q.x + (f1 - f0) - 1, y1 = q.y + (r1 - r0) - 1;
+    start_xy[2 * b] = q.x;
+    start_xy[2 * b + 1] = q.y;
+    end_xy[2 * b] = x1;
+    end_xy[2 * b + 1] = y1;
+    box_off[b] = f0;
+    c = ((x1 >> 4) - (q.x >> 4) + 1) * ((y1 >> 4) - (q.y >> 4) + 1);
+  } else if (fits && b == n_rects) {
+    box_off[b] = (int)n;
   }
   if (tile_cnt) {
-    if (wide) atomicAdd(&s_total, wide);  // integer adds: order-independent
+    if (b < capacity) tile_cnt[b] = c;
+    // the block's share of the 64-bit total (a rectangle touches a few thousand tiles at most: an int holds 256 of them)
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0 && s_total) atomicAdd(total64, s_total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = (unsigned long long)((long long)s_w[0] + s_w[1] + s_w[2] + s_w[3]);
   }
 }
 
 // info8 of gcp_rects_cut from what the stages left on the device
-__global__ void k_cut_finish(const int* __restrict__ info_rows /*[5]*/, const int* __restrict__ info_rects /*[2]*/,
-                             const unsigned long long* __restrict__ total64, i64 rect_capacity, int* __restrict__ info8) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_cut_finish(const int* __restrict__ info_rows /*[5]*/, const int* __restrict__ info_rects /*[2]*/,
+                                                    const unsigned long long* __restrict__ block_sum, i64 n_blocks, i64 rect_capacity,
+                                                    int* __restrict__ info8) {
+  __shared__ unsigned long long s_part[256];
+  unsigned long long part = 0;  // integer adds in a fixed order: the same total every time
+#pragma unroll 8
+  for (i64 j = threadIdx.x; j < n_blocks; j += 256) part += block_sum[j];
+  s_part[threadIdx.x] = part;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned long long k = 0;
+  for (int j = 0; j < 256; ++j) k += s_part[j];
   int flags = info_rows[4];
   const int n_rects = info_rects[0];
   if (flags == 0 && (i64)n_rects > rect_capacity) flags |= 4;
-  const unsigned long long k = *total64;
   if (flags == 0 && k > 0x7fffffffull) flags |= 8;
   info8[0] = info_rows[0]; info8[1] = info_rows[1]; info8[2] = info_rows[2]; info8[3] = info_rows[3];
   info8[4] = flags;
@@ -411,12 +450,13 @@ static size_t rows_ws_bytes(i64 n, const SlotLayout& L) {
 size_t gcp_rects_rows_workspace_bytes(int64_t n) { return rows_ws_bytes(n, slot_layout(n, n, 0, kSlotRowsMax)); }
 
 // the first cut; `slots_out` (optional) receives the slot region's address — dead once this call's launches are through
+// pool_fill_in: the one-call cut's own pool counter, cleared by it together with `info` (one fill for all its state words)
 static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, const SlotLayout& L, int64_t row_capacity, int32_t* row_start,
                            int32_t* row_xy, int32_t* info, void* ws, size_t ws_bytes, void* stream_, void** slots_out = nullptr,
-                           int2* row_packed = nullptr) {
+                           int2* row_packed = nullptr, unsigned long long* pool_fill_in = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || n > 0x7fffffffLL || row_capacity < 1 || !info) return GCP_ERR_INVALID_ARGUMENT;
-  GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));                       // rows, max x, max y, (min), not-boxes flags
+  if (!pool_fill_in) GCP_HIP(hipMemsetAsync(info, 0, 5 * sizeof(int), stream));    // rows, max x, max y, (min), not-boxes flags
   GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info + 3), 0x7fffffff, 1, stream));   // min coordinate
   if (n == 0) return GCP_OK;
   if (!rects_xy || (!row_packed && (!row_start || !row_xy)) || !ws) return GCP_ERR_INVALID_ARGUMENT;
@@ -425,12 +465,12 @@ static int rects_rows_impl(const void* rects_xy, bool wide, int64_t n, const Slo
   char* p = (char*)ws;
   int2* slots = (int2*)p; p += align256((size_t)(L.base(n_tiles) + 1) * sizeof(int2));
   int2* pool = (int2*)p; p += align256((size_t)(L.pool_rows + 1) * sizeof(int2));
-  unsigned long long* pool_fill = (unsigned long long*)p; p += 256;
+  unsigned long long* pool_fill = pool_fill_in ? pool_fill_in : (unsigned long long*)p; p += 256;
   int* pool_off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   if (slots_out) *slots_out = slots;
-  if (L.pool_rows > 0) GCP_HIP(hipMemsetAsync(pool_fill, 0, sizeof(unsigned long long), stream));
+  if (L.pool_rows > 0 && !pool_fill_in) GCP_HIP(hipMemsetAsync(pool_fill, 0, sizeof(unsigned long long), stream));
   if (wide) hipLaunchKernelGGL((k_rect_rows_local<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, pool, pool_fill,
                                pool_off, cnt, info);
   else hipLaunchKernelGGL((k_rect_rows_local<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rects_xy, (i64)n, L, slots, pool, pool_fill,
@@ -466,10 +506,10 @@ size_t gcp_rows_rectangles_workspace_bytes(int64_t n_rows) {
 
 // n_rows: the row count, or — with rows_dev, the first cut's info on the device — the row CAPACITY the grid has to cover
 static int rows_rectangles_impl(const Rows rows, int64_t n_rows, const int* rows_dev, int32_t* rect_row,
-                                int32_t* info, void* ws, size_t ws_bytes, void* stream_) {
+                                int32_t* info, void* ws, size_t ws_bytes, void* stream_, bool info_cleared = false) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows < 0 || n_rows > 0x7fffffffLL || !info) return GCP_ERR_INVALID_ARGUMENT;
-  GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));  // rectangles, (unused)
+  if (!info_cleared) GCP_HIP(hipMemsetAsync(info, 0, 2 * sizeof(int), stream));  // rectangles, (unused)
   if (n_rows == 0) return GCP_OK;
   if ((!rows.packed && (!rows.start || !rows.xy)) || !rect_row || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const i64 n_tiles = (n_rows + kRowTile - 1) / kRowTile;
@@ -477,13 +517,17 @@ static int rows_rectangles_impl(const Rows rows, int64_t n_rows, const int* rows
   char* p = (char*)ws;
   int* cnt = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
   int* off = (int*)p; p += align256((size_t)(n_tiles + 1) * sizeof(int));
-  hipLaunchKernelGGL((k_rows_rectangles<false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
-                     cnt, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  if (rows.packed) hipLaunchKernelGGL((k_rows_rectangles<false, true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
+                                      cnt, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  else hipLaunchKernelGGL((k_rows_rectangles<false, false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
+                          cnt, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, n_tiles, p, gcp_scan_i32_workspace_bytes(n_tiles), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL((k_rows_rectangles<true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
-                     (int*)nullptr, (const int*)off, rect_row, info);
+  if (rows.packed) hipLaunchKernelGGL((k_rows_rectangles<true, true>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
+                                      (int*)nullptr, (const int*)off, rect_row, info);
+  else hipLaunchKernelGGL((k_rows_rectangles<true, false>), dim3((unsigned)n_tiles), dim3(256), 0, stream, rows, (i64)n_rows, rows_dev,
+                          (int*)nullptr, (const int*)off, rect_row, info);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }
@@ -529,14 +573,15 @@ static CutWs cut_ws_layout(i64 n, const SlotLayout& L, i64 rect_capacity) {
   w.rect_ws = o; o += align256(gcp_rows_rectangles_workspace_bytes(rc));
   w.tile_cnt = o; o += align256((size_t)(rect_capacity + 1) * sizeof(int));
   w.scan_ws = o; o += align256(gcp_scan_i32_workspace_bytes(rect_capacity + 1));
-  w.info = o; o += 256;   // int[5] rows info, int[2] rectangles info at +32
-  w.total = o; o += 256;  // 64-bit total of the tile counts
+  w.info = o; o += 256;   // int[5] rows info, int[2] rectangles info at +32, the pool's fill counter at +64: one fill clears them
+  w.total = o; o += align256((size_t)((rect_capacity + 256) / 256 + 1) * sizeof(unsigned long long));  // per-block sums of the tile counts
   return w;
 }
 
 size_t gcp_rects_cut_workspace_bytes(int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows, int64_t rect_capacity) {
   if (n < 0 || rect_capacity < 0) return 0;
-  return cut_ws_layout(n, slot_layout(n, carry_front, carry_back, slot_rows, cut_pool_rows(n)), rect_capacity).total + 256;
+  const CutWs w = cut_ws_layout(n, slot_layout(n, carry_front, carry_back, slot_rows, cut_pool_rows(n)), rect_capacity);
+  return w.total + align256((size_t)((rect_capacity + 256) / 256 + 1) * sizeof(unsigned long long));
 }
 
 int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int64_t carry_front, int64_t carry_back, int32_t slot_rows,
@@ -544,8 +589,8 @@ int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int6
                   void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || n > 0x7fffffffLL || rect_capacity < 1 || rect_capacity > 0x7ffffff0LL || !info8) return GCP_ERR_INVALID_ARGUMENT;
-  GCP_HIP(hipMemsetAsync(info8, 0, 8 * sizeof(int), stream));
   if (n == 0) {
+    GCP_HIP(hipMemsetAsync(info8, 0, 8 * sizeof(int), stream));
     GCP_HIP(hipMemsetD32Async((hipDeviceptr_t)(info8 + 3), 0x7fffffff, 1, stream));
     if (box_off) GCP_HIP(hipMemsetAsync(box_off, 0, sizeof(int), stream));
     if (tile_off) GCP_HIP(hipMemsetAsync(tile_off, 0, sizeof(int), stream));
@@ -554,33 +599,34 @@ int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int6
   if (!rects_xy || !start_xy || !end_xy || !box_off || !tile_off || !ws) return GCP_ERR_INVALID_ARGUMENT;
   const SlotLayout L = slot_layout(n, carry_front, carry_back, slot_rows, cut_pool_rows(n));
   const CutWs w = cut_ws_layout(n, L, rect_capacity);
-  if (ws_bytes < w.total + 256 || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
+  if (ws_bytes < gcp_rects_cut_workspace_bytes(n, carry_front, carry_back, slot_rows, rect_capacity) || ((uintptr_t)ws & 255u)) return GCP_ERR_WORKSPACE;
   char* const base = (char*)ws;
   int2* const row_packed = (int2*)(base + w.row_xy);
   const Rows rows{nullptr, nullptr, row_packed};
   int* const info_rows = (int*)(base + w.info);
   int* const info_rects = info_rows + 8;
-  unsigned long long* const total64 = (unsigned long long*)(base + w.total);
+  unsigned long long* const block_sum = (unsigned long long*)(base + w.total);
+  unsigned long long* const pool_fill = (unsigned long long*)(base + w.info + 64);
+  GCP_HIP(hipMemsetAsync(info_rows, 0, 256, stream));  // every state word of the call (info8 itself is written whole at the end)
   int* const tile_cnt = (int*)(base + w.tile_cnt);
   const i64 row_cap = cut_row_capacity(n, L);
   void* slots = nullptr;
   int st = rects_rows_impl(rects_xy, rects_are_int64 != 0, n, L, row_cap, nullptr, nullptr, info_rows, base + w.rows_ws, rows_ws_bytes(n, L), stream_, &slots,
-                           row_packed);
+                           row_packed, pool_fill);
   if (st != GCP_OK) return st;
   // the rectangle list (one int per rectangle, at most one per row, + the sentinel) re-uses the slot region: its records
   // have all been moved to the rows by now (8 B per slot there, 4 B per row here)
   int* const rect_row = (int*)slots;
-  st = rows_rectangles_impl(rows, row_cap, info_rows, rect_row, info_rects, base + w.rect_ws, gcp_rows_rectangles_workspace_bytes(row_cap), stream_);
+  st = rows_rectangles_impl(rows, row_cap, info_rows, rect_row, info_rects, base + w.rect_ws, gcp_rows_rectangles_workspace_bytes(row_cap), stream_, true);
   if (st != GCP_OK) return st;
-  GCP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), stream));
-  const i64 box_blocks = (rect_capacity + 1 + 255) / 256 < 1024 ? (rect_capacity + 1 + 255) / 256 : 1024;
+  const i64 box_blocks = (rect_capacity + 1 + 255) / 256;
   hipLaunchKernelGGL(k_rectangle_boxes, dim3((unsigned)box_blocks), dim3(256), 0, stream, (const int*)rect_row, rows, (i64)0, (i64)n,
-                     (const int*)info_rects, (i64)rect_capacity, start_xy, end_xy, box_off, tile_cnt, total64);
+                     (const int*)info_rects, (i64)rect_capacity, start_xy, end_xy, box_off, tile_cnt, block_sum);
   GCP_HIP(hipGetLastError());
   st = gcp_exclusive_scan_i32(tile_cnt, tile_off, rect_capacity, base + w.scan_ws, gcp_scan_i32_workspace_bytes(rect_capacity + 1), stream_);
   if (st != GCP_OK) return st;
-  hipLaunchKernelGGL(k_cut_finish, dim3(1), dim3(64), 0, stream, (const int*)info_rows, (const int*)info_rects, (const unsigned long long*)total64,
-                     (i64)rect_capacity, info8);
+  hipLaunchKernelGGL(k_cut_finish, dim3(1), dim3(256), 0, stream, (const int*)info_rows, (const int*)info_rects, (const unsigned long long*)block_sum,
+                     box_blocks, (i64)rect_capacity, info8);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

@@ -55,6 +55,13 @@ using namespace gcp;
 #define GCP_STAGE_BWD 32
 #endif
 constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one block, 4 rows per wave
+// Measurement builds only (tools/build_variant.py -DGCP_TILE_SX=5|6): tiles of 32 x 8 / 64 x 4 pixels for the binning and the
+// tile-list walk — the blend kernels are NOT valid in such a build.  DESIGN.md §3.4 "the walk's access shape".
+#ifndef GCP_TILE_SX
+#define GCP_TILE_SX 4
+#endif
+constexpr int kTileSX = GCP_TILE_SX, kTileSY = 8 - GCP_TILE_SX;
+constexpr int kTileW = 1 << kTileSX, kTileH = 1 << kTileSY;
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
 constexpr int kStageBwd = GCP_STAGE_BWD;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kCkpt = kStageBwd;               // the forward saves every pixel's transmittance every kCkpt list entries
@@ -82,7 +89,7 @@ __device__ __forceinline__ float xchg_sum(bool second, float a, float b) {
 }
 
 struct TileGrid { int tx, ty; };
-inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTile - 1) / kTile, (H + 1 + kTile - 1) / kTile}; }
+inline TileGrid tile_grid(int W, int H) { return {(W + 1 + kTileW - 1) / kTileW, (H + 1 + kTileH - 1) / kTileH}; }
 
 // ------------------------------------------------------------------------------------------
 // Exclusive prefix sum of int32 (out has n+1 entries, out[n] = total).  Two small launches.
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void k_tile_count(const int* start, const int*
     Box b;
     int c = 0;
     if (load_box(start, end, g, W, H, b))
-      c = ((b.x1 >> 4) - (b.x0 >> 4) + 1) * ((b.y1 >> 4) - (b.y0 >> 4) + 1);
+      c = ((b.x1 >> kTileSX) - (b.x0 >> kTileSX) + 1) * ((b.y1 >> kTileSY) - (b.y0 >> kTileSY) + 1);
     cnt[g] = c;
     wide += (unsigned long long)c;
   }
@@ -197,8 +204,8 @@ __global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int 
   Box b;
   if (!load_box(start, end, g, W, H, b)) return;
   int e = off[g];
-  for (int ty = b.y0 >> 4; ty <= (b.y1 >> 4); ++ty)
-    for (int tx = b.x0 >> 4; tx <= (b.x1 >> 4); ++tx) {
+  for (int ty = b.y0 >> kTileSY; ty <= (b.y1 >> kTileSY); ++ty)
+    for (int tx = b.x0 >> kTileSX; tx <= (b.x1 >> kTileSX); ++tx) {
       key[e] = (unsigned)(ty * tiles_x + tx);
       val[e] = (unsigned)g;
       ++e;
@@ -1024,7 +1031,15 @@ __device__ __forceinline__ void walk_load(WalkBatch& b, unsigned long long& hits
 #pragma unroll
   for (int u = 0; u < kWalkBatch; ++u) {
     asm volatile("" :: "v"(e[u].x), "v"(e[u].y));  // the whole record is read ahead of the membership test
+#if GCP_TILE_SX == 4
     b.in[u] = ((unsigned)e[u].z & lane_bits) == lane_bits;
+#elif GCP_TILE_SX == 5
+    // 32 x 8 tiles, two pixel rows per wave: z = the box over the tile's 32 columns, w = over its 8 rows
+    b.in[u] = (((unsigned)e[u].z & lane_bits) != 0u) & (((unsigned)e[u].w & (1u << ly)) != 0u);
+#else
+    // 64 x 4 tiles, one pixel row per wave (the hit word has decided the row): (z, w) = the box over the tile's 64 columns
+    b.in[u] = ((((int)(threadIdx.x & 32) ? (unsigned)e[u].w : (unsigned)e[u].z) & lane_bits) != 0u);
+#endif
     const unsigned o = (unsigned)e[u].x + (unsigned)lxo + __umul24((unsigned)ly, (unsigned)e[u].y);
     b.off[u] = b.in[u] ? o : 0u;
 #if (GCP_WALK_DBG & 1)
@@ -1108,10 +1123,15 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
   // (row-major = a band of tile rows): horizontal and, but for the band edges, vertical neighbours share an L2.
   const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);
   if (tile < 0) return;
-  const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
+  const int tile_x0 = (tile % a.tiles_x) * kTileW, tile_y0 = (tile / a.tiles_x) * kTileH;
   constexpr int kUnit = WIDE ? 1 : 4;
-  const int lxo = (lane & 15) * kUnit, ly = w * 4 + (lane >> 4);
+  constexpr int kWaveRows = 64 / kTileW;  // pixel rows per wave: 4 (16 x 16 tiles), 2 (32 x 8), 1 (64 x 4)
+  const int lxo = (lane & (kTileW - 1)) * kUnit, ly = w * kWaveRows + (lane >> kTileSX);
+#if GCP_TILE_SX == 4
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + ly));
+#else
+  const unsigned lane_bits = 1u << (lane & 31);
+#endif
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   const int nrounds = (last - first + kWalkStage - 1) / kWalkStage;
   float acc = (MODE == 0) ? 1.0f : 0.0f;
@@ -1127,17 +1147,23 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
         Box b;
         load_box(a.start, a.end, g, a.W, a.H, b);
         const int wd = b.x1 - b.x0 + 1;
-        const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
-        const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
-        const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
+        const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTileW - 1);
+        const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTileH - 1);
+        const unsigned long long cm = (c1 >= c0) ? ((2ull << c1) - (1ull << c0)) : 0ull;
         rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
         // modulo 2^32: every pair of the list lies below 2^32 bytes (2^31 pairs when WIDE), whatever the tile's corner does
         const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 - b.x0);
-        s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(cm | (rm << 16)), 0);
+#if GCP_TILE_SX == 4
+        s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)((unsigned)cm | (rm << 16)), 0);
+#elif GCP_TILE_SX == 5
+        s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(unsigned)cm, (int)rm);
+#else
+        s_ent[lane] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(unsigned)cm, (int)(unsigned)(cm >> 32));
+#endif
       }
 #pragma unroll
       for (int w2 = 0; w2 < 4; ++w2) {
-        const unsigned long long touched = __ballot(((rm >> (4 * w2)) & 0xfu) != 0u);
+        const unsigned long long touched = __ballot(((rm >> (kWaveRows * w2)) & ((1u << kWaveRows) - 1u)) != 0u);
         if (lane == 0) s_hits[w2] = touched;
       }
     }

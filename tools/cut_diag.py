@@ -15,9 +15,23 @@ from tools.wrapper_bench import timeit  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    for cfg in (sys.argv[1:] or ["cfg3"]):
+    only = None
+    argv = sys.argv[1:]
+    if "--only" in argv:  # --only one | step: just that cut, ten times (for a kernel trace)
+        i = argv.index("--only")
+        only = argv[i + 1]
+        del argv[i:i + 2]
+    for cfg in (argv or ["cfg3"]):
         sc, rects, anti, grad = synthetic.make_scene_pairs(cfg, seed=0, device=dev)
         m = rects.size(0)
+        if only:
+            for _ in range(10):
+                if only == "one":
+                    raster._cut_rects_once(rects, False, 0, 0, 8)
+                else:
+                    raster.rects_to_boxes(rects, one_call=False)
+            torch.cuda.synchronize()
+            continue
         once = raster._cut_rects_once(rects, False, 0, 0, 8)
         out = {"workload": cfg, "pairs": m, "one_call": once if isinstance(once, str) or once is None else
                {"rects": int(once.start.size(0)), "K": once.n_tile_pairs, "width": once.width, "height": once.height}}

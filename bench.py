@@ -203,9 +203,9 @@ WRAPPER_BYTES = {
     "indexed scan": {"sorted key": 4, "permutation": 4, "gathered value": 4, "scattered inclusive value": 4},
     "compaction": {"count pass reads the inclusive values": 4, "write pass reads inclusive + self": 8, "mask": 1, "kept values": 4},
 }
-# (the walk counts the zeros it writes, so this compaction has no counting pass)
-WRAPPER_BOX_BYTES = {"tile-list walk": {"value read": 4, "inclusive value written": 4},
-                     "compaction": {"write pass reads inclusive + self": 8, "mask": 1, "kept values": 4}}
+# the walk writes the FINAL values (inclusive / self, inclusive - self) and clears the mask byte of a pair it drops: when nothing
+# drops — the usual case, and this workload's — there is no compaction pass (else + 5 B read, 4 B written per pair)
+WRAPPER_BOX_BYTES = {"tile-list walk": {"value read": 4, "final value written": 4}, "mask": {"fill with ones": 1}}
 # the default route: the rect list cut back into rectangles (one read of the list; its row / rectangle records are ~1/13 of a
 # pair each, rounded up to 1 B/pair), then the boxes route
 WRAPPER_AUTO_BYTES = {"rect list -> rows -> rectangles": {"rects read once": 8, "row and rectangle records": 1}, **WRAPPER_BOX_BYTES}
@@ -249,8 +249,7 @@ def wrapper_level(dev, workload):
         return ts[len(ts) // 2]
 
     # the reference's own call, nothing but (rects, values, flag): the list is cut back into boxes and walked
-    # (the first calls also settle the caching allocator's pool — 1.3 GB of slot workspace per call at cfg3 — and follow a
-    # stretch of host work: warm up for 0.1 s)
+    # (the first calls also settle the caching allocator's pool and follow a stretch of host work: warm up for 0.1 s)
     t_a5_auto = timed(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters=7, warmup=4, warm_s=0.1)
     t_a6_auto = timed(lambda: ck.grad_cumsum(rects, grad), iters=7, warmup=2)
     t_cut = timed(lambda: raster.rects_to_boxes(rects))
@@ -283,10 +282,20 @@ def wrapper_level(dev, workload):
     t_bin = timed(lambda: raster.bin_tiles(sc["start"], sc["end"], w, h))
     bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
     boff = raster.box_offsets(sc["start"], sc["end"], w, h)
-    t_walk = timed(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True))
-    incl_b, dropped = raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True)
-    t_comp_b = timed(lambda: raster.compact_finish(incl_b, anti, 0, dropped=dropped))
-    del incl_b, dropped
+    t_walk = timed(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, anti, 0))
+    fin_b, keep_b, dropped = raster.finish_boxes(bins, sc["start"], sc["end"], boff, anti, 0)
+    t_comp_b = timed(lambda: raster.compact_kept(fin_b, keep_b, dropped))
+    n_dropped = m - int(raster.compact_kept(fin_b, keep_b, dropped)[0].numel())
+    del fin_b, keep_b, dropped
+    # the cut of the default route: one call, one read-back; and its binning, whose counting pass the cut has done
+    rb = raster.rects_to_boxes(rects)
+    t_bin_counted = timed(lambda: rb.bin()) if rb is not None else None
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    held = torch.cuda.memory_allocated(dev)
+    raster.rects_to_boxes(rects)
+    cut_scratch = (torch.cuda.max_memory_allocated(dev) - held) / m
+    del rb
     b_rects = sum(sum(v.values()) for v in WRAPPER_BYTES.values())
     b_boxes = sum(sum(v.values()) for v in WRAPPER_BOX_BYTES.values())
     b_auto = sum(sum(v.values()) for v in WRAPPER_AUTO_BYTES.values())
@@ -299,6 +308,7 @@ def wrapper_level(dev, workload):
     return {
         "what": "_create_alpha_brend / grad_cumsum (gs_model.py:544-566, :716-722) on one camera's pair list: Gaussian-major rects, "
                 "stable sort by pixel key, per-pixel scan, un-sort, != 0 compaction, / self | - self",
+        "default_route": "rect list cut back into boxes (one call), binned, walked; the walk writes final values and the mask",
         "workload": f"{workload} scene: {w + 1}x{h + 1}, {int(sc['start'].size(0))} Gaussians",
         "pairs": m,
         "kept_pairs": kept,
@@ -315,8 +325,13 @@ def wrapper_level(dev, workload):
         "create_alpha_brend_int64_rects_ms": t_a5_i64,
         "with_prepared_rects_ms": {"create_alpha_brend": t_a5_prep, "grad_cumsum": t_a6_prep,
                                    "what": "cuda_kernel.PreparedRects(rects): cut + binning done once for the calls of one step"},
-        "stages_ms": {"rects_to_boxes (rows, rectangles, boxes)": t_cut, "bin_tiles": t_bin,
-                      "tile-list walk (counts the zeros it writes)": t_walk, "compact_finish (no counting pass)": t_comp_b},
+        "stages_ms": {"rects_to_boxes (rows, rectangles, boxes, tiles per box: one call, one read-back)": t_cut,
+                      "bin_tiles (counting pass done by the cut)": t_bin_counted,
+                      "tile-list walk writing final values + mask": t_walk,
+                      "kept count + the read-back that sizes the result (no compaction pass: nothing dropped)": t_comp_b},
+        "dropped_pairs": n_dropped,
+        "device_to_host_reads_per_call": 2,
+        "cut_scratch_bytes_per_pair": cut_scratch,
         "byte_model": WRAPPER_AUTO_BYTES,
         "general_sort_route": {
             "what": "route='sort': any list of pixel coordinates — key-in-sort stable radix sort, one indexed scan, the same compaction",
@@ -338,8 +353,8 @@ def wrapper_level(dev, workload):
             "create_alpha_brend_boxes_ms": t_a5b,
             "grad_cumsum_boxes_ms": t_a6b,
             "pairs_per_s": m / (t_a5b * 1e-3),
-            "stages_ms": {"bin_tiles": t_bin, "tile-list walk (counts the zeros it writes)": t_walk,
-                          "compact_finish (no counting pass)": t_comp_b},
+            "stages_ms": {"bin_tiles": t_bin, "tile-list walk writing final values + mask": t_walk,
+                          "kept count + read-back (no compaction pass: nothing dropped)": t_comp_b},
             "tile_entries": bins.n_tile_pairs,
             "roofline": roof(b_boxes, t_a5b),
             "byte_model": WRAPPER_BOX_BYTES,

@@ -50,6 +50,7 @@ __all__ = [
     "tile_capacity",
     "capacity_exceeded",
     "GraphedStep",
+    "capture_leaf",
 ]
 
 # Capture-safe mode of the Function (no device->host read inside forward / backward): the caller bounds the number of
@@ -101,6 +102,53 @@ def capacity_exceeded():
     return hit
 
 
+def capture_leaf(t):
+    """Mark `t` as an autograd leaf created FOR a graph capture — under the capturing stream, with no history from eager steps
+    (`p.detach().requires_grad_()` is one) — so that `custom_autograd_grouped_cumprod` accepts it inside `torch.cuda.graph`
+    (see `_refuse_stale_leaves_in_capture`).  `GraphedStep` marks its own aliases.  Returns `t`."""
+    t._gcp_capture_leaf = True
+    return t
+
+
+def _refuse_stale_leaves_in_capture(*tensors):
+    """While the current stream is capturing, every autograd leaf the differentiable inputs descend from must have been
+    made for this capture (`capture_leaf`; `GraphedStep` does it).  A leaf that has been through an eager step keeps its
+    AccumulateGrad node — bound to the stream of that step, alive as long as any output of it is — and a backward captured on
+    another stream then pulls that stream into the capture: `capture_end` of this ROCm stack dies with SIGSEGV
+    (tools/capture_repro.py).  Python cannot see a node's stream, so the test is the conservative one: an
+    unmarked leaf raises — a RuntimeError that says how to proceed instead of a crash at the end of the capture."""
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return
+    stack, seen = [], set()
+
+    def check(leaf):
+        if leaf.requires_grad and not getattr(leaf, "_gcp_capture_leaf", False):
+            raise RuntimeError(
+                "custom_autograd_grouped_cumprod inside torch.cuda.graph: a differentiable input descends from an autograd leaf "
+                f"(shape {tuple(leaf.shape)}) that was not created for this capture.  If that leaf has been through an eager step "
+                "whose outputs are still alive, its AccumulateGrad node belongs to another stream and capture_end crashes on this "
+                "ROCm stack.  Capture the step with cuda_kernel.GraphedStep(fn, params, capacity=...) — it traces through fresh "
+                "aliases of the parameters — or, if you made fresh leaves yourself (p.detach().requires_grad_() under the "
+                "capturing stream), mark them with cuda_kernel.capture_leaf(t).")
+
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            if t.grad_fn is None:
+                check(t)
+            else:
+                stack.append(t.grad_fn)
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, "variable", None)  # AccumulateGrad: the leaf it accumulates into
+        if isinstance(var, torch.Tensor):
+            check(var)
+        for nxt, _ in fn.next_functions:
+            stack.append(nxt)
+
+
 class GraphedStep:
     """One training-step body — `fn(*params)` -> loss, or a tuple whose first entry is the loss — with its backward,
     captured into ONE HIP graph and replayed with `replay()` -> (outputs of fn, gradients w.r.t. params).
@@ -140,7 +188,7 @@ class GraphedStep:
 
     def _trace(self, bounded=True):
         with (self._bound() if bounded else contextlib.nullcontext()):
-            leaves = [p.detach().requires_grad_(True) for p in self.params]
+            leaves = [capture_leaf(p.detach().requires_grad_(True)) for p in self.params]
             out = self._fn(*leaves)
             loss = out[0] if isinstance(out, (tuple, list)) else out
             grads = torch.autograd.grad(loss, leaves, allow_unused=True)
@@ -430,6 +478,7 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
     @staticmethod
     def forward(ctx, boxsize, batch, startpoint, endpoint, mean, variance_inverse, opacity, l_d, image_width,
                 image_height):
+        _refuse_stale_leaves_in_capture(mean, variance_inverse, opacity, l_d)
         with torch.no_grad():
             w, h = int(image_width), int(image_height)
             bins = _raster.bin_tiles(startpoint, endpoint, w, h, capacity=_capacity)

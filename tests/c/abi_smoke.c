@@ -1,8 +1,9 @@
 /* abi_smoke.c — a plain C program on the C ABI (no Python, no torch, no C++): what a host written in
  * another language would do through its FFI.  Builds with gcc against include/grouped_cumprod_hip.h and
  * libgrouped_cumprod_hip.so; device memory comes from the HIP runtime's C API.
- * Runs the reference's known-answer test (reference: cuda_test.py:19-34), a 1M-element scan, and the three-stage
- * _create_alpha_brend (gs_model.py:544-566) on the reference's worked example for it (uitility.py:383-393).
+ * Runs the reference's known-answer test (reference: cuda_test.py:19-34), a 1M-element scan, the three-stage general route
+ * of _create_alpha_brend (gs_model.py:544-566) on the reference's worked example for it (uitility.py:383-393), the rect cut
+ * step by step, and the default route of _create_alpha_brend (one-call cut, binning, walk, kept count) on two boxes.
  * Exit code 0 = pass.  With argument "link-only" it only checks that the symbols resolve (no GPU). */
 #include <math.h>
 #include <stdio.h>
@@ -128,6 +129,65 @@ static int run_rect_cut(void) {
   return 0;
 }
 
+/* The DEFAULT route of _create_alpha_brend (gs_model.py:544-566) through the C ABI alone, two device->host reads:
+ * gcp_rects_cut (rows, rectangles, boxes, tiles per box; read info8) -> gcp_bin_tiles_fill -> gcp_pairs_finish_boxes (the walk
+ * writes final values + mask) -> gcp_compact_kept_count (read the kept count) -> gcp_compact_kept_write.
+ * Two boxes in depth order, A = [0,9] x [0,7] with factor 0.5 (0 at pixel (6,4): opaque) and B = [5,14] x [3,10] with factor
+ * 0.25: A's pairs see transmittance 1, B's 0.5 where A lies in front and 1 elsewhere; the opaque pair and B's pair behind it
+ * have an inclusive product of exactly 0 and are dropped (gs_model.py:560). */
+static int run_default_route(void) {
+  enum { NA = 80, NB = 80, N = 160, CAP = 8 };
+  int32_t rects[2 * N]; float a[N], want[N]; uint8_t want_keep[N];
+  int64_t p = 0;
+  for (int y = 0; y <= 7; ++y) for (int x = 0; x <= 9; ++x, ++p) {
+    rects[2 * p] = x; rects[2 * p + 1] = y;
+    const int opaque = (x == 6 && y == 4);
+    a[p] = opaque ? 0.0f : 0.5f; want[p] = 1.0f; want_keep[p] = !opaque;
+  }
+  for (int y = 3; y <= 10; ++y) for (int x = 5; x <= 14; ++x, ++p) {
+    rects[2 * p] = x; rects[2 * p + 1] = y;
+    const int behind_a = (x <= 9 && y <= 7);
+    a[p] = 0.25f; want[p] = behind_a ? 0.5f : 1.0f; want_keep[p] = !(x == 6 && y == 4);
+  }
+  int32_t *d_r, *d_s, *d_e, *d_boff, *d_toff, *d_info, *d_tstart, *d_tlist, *d_drop, *d_cnt; float *d_a, *d_fin, *d_val; uint8_t* d_keep;
+  void *ws_cut, *ws_bin, *ws_cmp;
+  const size_t b_cut = gcp_rects_cut_workspace_bytes(N, 0, 0, 512, CAP), b_cmp = gcp_compact_kept_workspace_bytes(N);
+  if (hipMalloc((void**)&d_r, sizeof rects) || hipMalloc((void**)&d_a, sizeof a) || hipMalloc((void**)&d_s, CAP * 8) || hipMalloc((void**)&d_e, CAP * 8) ||
+      hipMalloc((void**)&d_boff, (CAP + 1) * 4) || hipMalloc((void**)&d_toff, (CAP + 1) * 4) || hipMalloc((void**)&d_info, 32) ||
+      hipMalloc(&ws_cut, b_cut) || hipMalloc(&ws_cmp, b_cmp)) return 1;
+  hipMemcpy(d_r, rects, sizeof rects, 1); hipMemcpy(d_a, a, sizeof a, 1);
+  CHECK(gcp_rects_cut(d_r, 0, N, 0, 0, 512, CAP, d_s, d_e, d_boff, d_toff, d_info, ws_cut, b_cut, NULL));
+  hipDeviceSynchronize();
+  int32_t info[8]; hipMemcpy(info, d_info, 32, 2);  /* read 1: {rows, max x, max y, min, flags, rectangles, K, 0} */
+  const int32_t want_info[8] = {16, 14, 10, 0, 0, 2, 2, 0};
+  if (memcmp(info, want_info, 32)) { printf("default route: info %d %d %d %d %d %d %d\n", info[0], info[1], info[2], info[3], info[4], info[5], info[6]); return 1; }
+  const int32_t w = info[1], h = info[2], n_rects = info[5], K = info[6];
+  int32_t tx = 0, ty = 0;
+  CHECK(gcp_tile_grid(w, h, &tx, &ty));
+  const size_t b_bin = gcp_bin_workspace_bytes(n_rects, K);
+  if (hipMalloc((void**)&d_tstart, (size_t)(tx * ty + 1) * 4) || hipMalloc((void**)&d_tlist, (size_t)K * 4) || hipMalloc(&ws_bin, b_bin) ||
+      hipMalloc((void**)&d_fin, N * 4) || hipMalloc((void**)&d_val, N * 4) || hipMalloc((void**)&d_keep, N) || hipMalloc((void**)&d_drop, 4) ||
+      hipMalloc((void**)&d_cnt, 4)) return 1;
+  CHECK(gcp_bin_tiles_fill(d_s, d_e, n_rects, w, h, d_toff, K, d_tstart, d_tlist, ws_bin, b_bin, NULL));
+  CHECK(gcp_pairs_finish_boxes(d_s, d_e, n_rects, w, h, d_tstart, d_tlist, d_boff, d_a, d_fin, d_keep, N, 0, d_drop, NULL));
+  CHECK(gcp_compact_kept_count(d_keep, d_drop, N, 0, N, d_cnt, ws_cmp, b_cmp, NULL));
+  hipDeviceSynchronize();
+  int32_t kept = -1; hipMemcpy(&kept, d_cnt, 4, 2);  /* read 2: sizes the result, as the reference's output[mask] does */
+  if (kept != N - 2) { printf("default route: kept %d of %d\n", kept, N); return 1; }
+  CHECK(gcp_compact_kept_write(d_fin, d_keep, 0, N, d_val, ws_cmp, b_cmp, NULL));
+  hipDeviceSynchronize();
+  float val[N]; uint8_t keep[N];
+  hipMemcpy(val, d_val, (size_t)kept * 4, 2); hipMemcpy(keep, d_keep, N, 2);
+  int k = 0;
+  for (int i = 0; i < N; ++i) {
+    if (keep[i] != want_keep[i]) { printf("default route: mask differs at %d\n", i); return 1; }
+    if (keep[i] && val[k++] != want[i]) { printf("default route: value %d is %g, expected %g\n", i, val[k - 1], want[i]); return 1; }
+  }
+  hipFree(d_r); hipFree(d_a); hipFree(d_s); hipFree(d_e); hipFree(d_boff); hipFree(d_toff); hipFree(d_info); hipFree(d_tstart); hipFree(d_tlist);
+  hipFree(d_fin); hipFree(d_val); hipFree(d_keep); hipFree(d_drop); hipFree(d_cnt); hipFree(ws_cut); hipFree(ws_bin); hipFree(ws_cmp);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (gcp_abi_version() != GCP_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
   if (argc > 1 && strcmp(argv[1], "link-only") == 0) { printf("link ok, tile = %d elements\n", gcp_tile_elems()); return 0; }
@@ -135,6 +195,7 @@ int main(int argc, char** argv) {
   if (run_big()) return 1;
   if (run_alpha_brend()) return 1;
   if (run_rect_cut()) return 1;
+  if (run_default_route()) return 1;
   printf("abi_smoke ok\n");
   return 0;
 }

@@ -627,3 +627,64 @@ def test_capacity_overflow_is_reported_by_every_replay_of_a_captured_step(device
     st["end"].copy_(small)
     gs.replay()
     assert not ck.capacity_exceeded()
+
+
+_STALE_CAPTURE = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import cuda_kernel as ck
+from tests.util import make_scene
+
+dev = torch.device("cuda", 0)
+sc = make_scene(200, 63, 47, 9, seed=5)
+w, h = sc["width"], sc["height"]
+ints = [sc[k].to(dev) for k in ("boxsize", "start", "end", "mean")]
+op = sc["opacity"].to(dev).requires_grad_(True)
+vinv = sc["vinv"].to(dev).requires_grad_(True)
+l_d = sc["l_d"].to(dev).requires_grad_(True)
+batch = torch.tensor([200], device=dev)
+
+def step(v, o, l):
+    img = ck.custom_autograd_grouped_cumprod.apply(ints[0], batch, ints[1], ints[2], ints[3], v, o * 1.0, l, w, h)
+    return torch.autograd.grad(img.square().sum(), [v, o, l])
+
+eager = step(vinv, op, l_d)          # an eager step on the default stream; `kept` keeps its graph (and the leaves' nodes) alive
+kept = (op * 2.0).sum()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+mode = sys.argv[2]
+with ck.tile_capacity(8 * 200, dev):
+    with torch.cuda.stream(side):
+        pass
+    graph = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(graph, stream=side):
+            if mode == "stale":
+                step(vinv, op, l_d)                  # the leaves of the eager step: refused, not crashed on
+            else:
+                fresh = [ck.capture_leaf(t.detach().requires_grad_(True)) for t in (vinv, op, l_d)]
+                got = step(*fresh)
+    except RuntimeError as e:
+        print("RAISED", "GraphedStep" in str(e) and "capture_leaf" in str(e))
+        sys.exit(0)
+graph.replay()
+torch.cuda.synchronize()
+print("CAPTURED", all(torch.allclose(a, b, rtol=1e-4, atol=1e-5) for a, b in zip(got, eager)))
+'''
+
+
+@pytest.mark.parametrize("mode", ["stale", "marked"])
+def test_bare_capture_of_the_function_refuses_leaves_of_eager_steps(device, tmp_path, mode):
+    """A bare `torch.cuda.graph` around the Function after eager steps used to end in SIGSEGV inside capture_end (stale
+    AccumulateGrad nodes pull the default stream into the capture: tools/capture_repro.py).  The Function now refuses leaves
+    that were not made for the capture with a RuntimeError that names `GraphedStep` and `capture_leaf`; fresh leaves marked
+    with `capture_leaf` capture and replay to the eager gradients.  (In a subprocess: a crash must not take the suite down.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "capture_case.py"
+    script.write_text(_STALE_CAPTURE)
+    res = subprocess.run([sys.executable, "-X", "faulthandler", str(script), root, mode], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert ("RAISED True" if mode == "stale" else "CAPTURED True") in res.stdout, res.stdout + res.stderr[-2000:]

@@ -60,8 +60,17 @@ constexpr int kTile = 16;           // tile edge in pixels; 256 pixels = one blo
 #ifndef GCP_TILE_SX
 #define GCP_TILE_SX 4
 #endif
-constexpr int kTileSX = GCP_TILE_SX, kTileSY = 8 - GCP_TILE_SX;
+// -DGCP_TILE_SX=5 -DGCP_TILE_SY=4: "super-tiles" of 32 x 16 pixels walked by 512-thread blocks — eight waves of 4 rows x 16
+// columns each, two side by side — so that both pieces of a box row that crosses a 16-pixel column boundary are read and
+// written by one block in the same round.
+#ifndef GCP_TILE_SY
+#define GCP_TILE_SY (8 - GCP_TILE_SX)
+#endif
+constexpr int kTileSX = GCP_TILE_SX, kTileSY = GCP_TILE_SY;
 constexpr int kTileW = 1 << kTileSX, kTileH = 1 << kTileSY;
+constexpr int kWalkThreads = kTileW * kTileH;           // one lane per pixel of the walk's tile
+constexpr bool kWalkSuper = kWalkThreads == 512;
+static_assert(kWalkThreads == 256 || (kTileSX == 5 && kTileSY == 4), "walk tiles: 256 pixels, or 32 x 16 super-tiles");
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
 constexpr int kStageBwd = GCP_STAGE_BWD;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kCkpt = kStageBwd;               // the forward saves every pixel's transmittance every kCkpt list entries
@@ -1103,16 +1112,16 @@ __device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict_
 
 template <int MODE, bool WIDE, int OUT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 // (pinned to eight waves per SIMD the byte-offset form fits 63 VGPRs without a spill — and runs no faster: 0.62 ms either way)
-__global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
-                                                          const float* __restrict__ x, float* __restrict__ out,
-                                                          int* __restrict__ dropped, unsigned char* __restrict__ keep, int n_tiles,
-                                                          int xcd_remap) {
+__global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
+                                                                   const float* __restrict__ x, float* __restrict__ out,
+                                                                   int* __restrict__ dropped, unsigned char* __restrict__ keep,
+                                                                   int n_tiles, int xcd_remap) {
   // a staged entry: x = position of the tile's first pixel in the entry's box run (box_off + (tile_y0 - y0) * width +
   // (tile_x0 - x0), may lie before the run), y = box width — both in bytes unless WIDE —, z = the box as bits over the
   // tile's columns (0-15) and rows (16-31).  A lane's pair is x + row * y + column, and it is in the box when both of
   // its bits are set: membership is one AND and one compare.
   __shared__ int4 s_ent_[kWalkStage + 1];
-  __shared__ unsigned long long s_hits[4];
+  __shared__ unsigned long long s_hits[kWalkThreads / 64];
   int4* const s_ent = s_ent_ + 1;  // record -1: no bits set, what a batch reads for the slots past its last hit
   if (threadIdx.x == 0) s_ent[-1] = make_int4(0, 0, 0, 0);
   const int lane = threadIdx.x & 63;
@@ -1125,12 +1134,14 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
   if (tile < 0) return;
   const int tile_x0 = (tile % a.tiles_x) * kTileW, tile_y0 = (tile / a.tiles_x) * kTileH;
   constexpr int kUnit = WIDE ? 1 : 4;
-  constexpr int kWaveRows = 64 / kTileW;  // pixel rows per wave: 4 (16 x 16 tiles), 2 (32 x 8), 1 (64 x 4)
-  const int lxo = (lane & (kTileW - 1)) * kUnit, ly = w * kWaveRows + (lane >> kTileSX);
+  // pixel rows per wave: 4 (16 x 16 tiles, and super-tiles: two waves side by side), 2 (32 x 8), 1 (64 x 4)
+  constexpr int kWaveCols = kWalkSuper ? 16 : kTileW, kWaveRows = 64 / kWaveCols, kWavesAcross = kTileW / kWaveCols;
+  const int lx = (w % kWavesAcross) * kWaveCols + (lane & (kWaveCols - 1));
+  const int lxo = lx * kUnit, ly = (w / kWavesAcross) * kWaveRows + lane / kWaveCols;
 #if GCP_TILE_SX == 4
   const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + ly));
 #else
-  const unsigned lane_bits = 1u << (lane & 31);
+  const unsigned lane_bits = 1u << (lx & 31);
 #endif
   const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
   const int nrounds = (last - first + kWalkStage - 1) / kWalkStage;
@@ -1141,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
     const int cnt = min(kWalkStage, last - base);
     __syncthreads();
     if (w == 0) {  // wave 0 stages the round (a fifth wave staging one round ahead of the walkers: measured 6 % slower)
-      unsigned rm = 0u;
+      unsigned rm = 0u, cmask32 = 0u;
       if (lane < cnt) {
         const i64 g = a.tile_list[base + lane];
         Box b;
@@ -1151,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
         const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTileH - 1);
         const unsigned long long cm = (c1 >= c0) ? ((2ull << c1) - (1ull << c0)) : 0ull;
         rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
+        cmask32 = (unsigned)cm;
         // modulo 2^32: every pair of the list lies below 2^32 bytes (2^31 pairs when WIDE), whatever the tile's corner does
         const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 - b.x0);
 #if GCP_TILE_SX == 4
@@ -1162,8 +1174,10 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
 #endif
       }
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        const unsigned long long touched = __ballot(((rm >> (kWaveRows * w2)) & ((1u << kWaveRows) - 1u)) != 0u);
+      for (int w2 = 0; w2 < kWalkThreads / 64; ++w2) {
+        const bool rows_hit = ((rm >> (kWaveRows * (w2 / kWavesAcross))) & ((1u << kWaveRows) - 1u)) != 0u;
+        const bool cols_hit = !kWalkSuper || ((cmask32 >> (16 * (w2 % kWavesAcross))) & 0xffffu) != 0u;
+        const unsigned long long touched = __ballot(rows_hit && cols_hit);
         if (lane == 0) s_hits[w2] = touched;
       }
     }
@@ -1180,6 +1194,101 @@ __global__ __launch_bounds__(256) void k_pairs_scan_boxes(const BlendArgs a, con
         walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
         if (!hits) { walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
         walk_load<MODE, WIDE>(A, hits, s_ent, lane_bits, ly, lxo, x);
+        walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
+      }
+    }
+  }
+}
+
+// ---- the walk on PRECOMPUTED entry records: no staging wave, no barrier, no LDS ------------------------------------------
+// k_walk_records turns every (tile, box) entry of the tile lists into the 16-byte record the walk needs — {position of the
+// tile's first pixel in the box's run, box width (both in bytes unless WIDE), the box as column / row bits of the tile} —
+// once (a PreparedRects keeps them for the forward's and the backward's call).  The walk then needs nothing but the records:
+// every wave loads the 64 records of a round itself (one coalesced 1 KB load, the next round's already in flight), finds the
+// entries that reach its four pixel rows with one ballot, and hands a listed record to its lanes with three v_readlane —
+// the per-lane arithmetic takes them as scalar operands.  The staged form above spends two DEPENDENT global loads per round
+// (tile list -> boxes) in one wave while the other three wait at a barrier.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_walk_records(const BlendArgs a, const int* __restrict__ box_off, int4* __restrict__ rec,
+                                                      int n_tiles) {
+  const int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
+  constexpr int kUnit = WIDE ? 1 : 4;
+  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
+  for (int j = first + (int)threadIdx.x; j < last; j += 256) {
+    const i64 g = a.tile_list[j];
+    Box b;
+    load_box(a.start, a.end, g, a.W, a.H, b);
+    const int wd = b.x1 - b.x0 + 1;
+    const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
+    const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
+    const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
+    const unsigned rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
+    const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 - b.x0);
+    rec[j] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(cm | (rm << 16)), 0);
+  }
+}
+
+template <int MODE, bool WIDE>
+__device__ __forceinline__ void walk_load_r(WalkBatch& b, unsigned long long& hits, const int4& cur, unsigned lane_bits, int ly, int lxo,
+                                            const float* __restrict__ x) {
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {
+    int k;  // scalar: the next set bit, -1 when none is left
+    if (MODE == 2) {
+      k = hits ? 63 - __builtin_clzll(hits) : -1;
+      hits &= ~(1ull << (k & 63));
+    } else {
+      k = hits ? __builtin_ctzll(hits) : -1;
+      hits &= hits - 1ull;
+    }
+    const int ex = __builtin_amdgcn_readlane(cur.x, k & 63), ey = __builtin_amdgcn_readlane(cur.y, k & 63);
+    const unsigned ez = k < 0 ? 0u : (unsigned)__builtin_amdgcn_readlane(cur.z, k & 63);  // no bits: the slot past the last hit
+    b.in[u] = (ez & lane_bits) == lane_bits;
+    const unsigned o = (unsigned)ex + (unsigned)lxo + __umul24((unsigned)ly, (unsigned)ey);
+    b.off[u] = b.in[u] ? o : 0u;
+    b.v[u] = WIDE ? x[b.off[u]] : *(const float*)((const char*)x + b.off[u]);
+  }
+}
+
+template <int MODE, bool WIDE, int OUT>
+__global__ __launch_bounds__(256) void k_pairs_walk_records(const BlendArgs a, const int4* __restrict__ rec, const float* __restrict__ x,
+                                                            float* __restrict__ out, int* __restrict__ dropped,
+                                                            unsigned char* __restrict__ keep, int n_tiles, int xcd_remap) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);  // XCD x takes the x-th contiguous eighth of the tiles
+  if (tile < 0) return;
+  constexpr int kUnit = WIDE ? 1 : 4;
+  const int lxo = (lane & 15) * kUnit, ly = w * 4 + (lane >> 4);
+  const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + ly));
+  const int first = a.tile_start[tile], n = a.tile_start[tile + 1] - first;
+  if (n <= 0) return;
+  const int nrounds = (n + kWalkStage - 1) / kWalkStage;
+  float acc = (MODE == 0) ? 1.0f : 0.0f;
+  // the records of the first round; every later round's are loaded one round ahead (an index past the list is clamped into
+  // it: straight-line loads, the value is never used)
+  int4 nxt = rec[first + min(((MODE == 2) ? (nrounds - 1) : 0) * kWalkStage + lane, n - 1)];
+  for (int q0 = 0; q0 < nrounds; ++q0) {
+    const int q = (MODE == 2) ? (nrounds - 1 - q0) : q0;
+    const int cnt = min(kWalkStage, n - q * kWalkStage);
+    const int4 cur = nxt;
+    {
+      const int qn = (MODE == 2) ? (q - 1) : (q + 1);
+      nxt = rec[first + min(max(qn, 0) * kWalkStage + lane, n - 1)];
+    }
+    const unsigned rm = (unsigned)cur.z >> 16;
+    unsigned long long hits = __ballot(lane < cnt && ((rm >> (4 * w)) & 0xfu) != 0u);
+    if (hits) {
+      WalkBatch A, B;
+      walk_load_r<MODE, WIDE>(A, hits, cur, lane_bits, ly, lxo, x);
+      for (;;) {
+        if (!hits) { walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep); break; }
+        walk_load_r<MODE, WIDE>(B, hits, cur, lane_bits, ly, lxo, x);
+        walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
+        if (!hits) { walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
+        walk_load_r<MODE, WIDE>(A, hits, cur, lane_bits, ly, lxo, x);
         walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
       }
     }
@@ -1871,9 +1980,34 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   if ((int64_t)width + 1 >= (wide ? (1LL << 24) : (1LL << 22))) return GCP_ERR_INVALID_ARGUMENT;
   const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
-  const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(256);
+  const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(kWalkThreads);
+#ifndef GCP_WALK_RECORDS
+#define GCP_WALK_RECORDS 0  // measurement builds: 1 = the walk on precomputed entry records (internal scratch: not for production)
+#endif
+#if GCP_WALK_RECORDS
+  static void* rec_buf = nullptr;
+  static size_t rec_cap = 0;
+  int K_host = 0;
+  GCP_HIP(hipMemcpyAsync(&K_host, tile_start + n_tiles, sizeof(int), hipMemcpyDeviceToHost, stream));
+  GCP_HIP(hipStreamSynchronize(stream));
+  if ((size_t)K_host * 16 > rec_cap) {
+    if (rec_buf) (void)hipFree(rec_buf);
+    rec_cap = (size_t)K_host * 16 * 2 + 4096;
+    GCP_HIP(hipMalloc(&rec_buf, rec_cap));
+  }
+  static const int rec_every = [] { const char* e = getenv("GCP_WALK_RECORDS_EVERY_CALL"); return (e && *e) ? atoi(e) : 1; }();
+  static const void* rec_for = nullptr;
+  if (rec_every || rec_for != (const void*)tile_list) {
+    if (wide) hipLaunchKernelGGL((k_walk_records<true>), dim3((unsigned)n_tiles), block, 0, stream, a, box_off, (int4*)rec_buf, n_tiles);
+    else hipLaunchKernelGGL((k_walk_records<false>), dim3((unsigned)n_tiles), block, 0, stream, a, box_off, (int4*)rec_buf, n_tiles);
+    rec_for = tile_list;
+  }
+#define GCP_WALK(M, W_, O_) \
+  hipLaunchKernelGGL((k_pairs_walk_records<M, W_, O_>), grid, block, 0, stream, a, (const int4*)rec_buf, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
+#else
 #define GCP_WALK(M, W_, O_) \
   hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, O_>), grid, block, 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
+#endif
 #define GCP_WALK_OUT(M, W_)                                  \
   do {                                                       \
     if (out_mode == kWalkFinal) GCP_WALK(M, W_, kWalkFinal); \

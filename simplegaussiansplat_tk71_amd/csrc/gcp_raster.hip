@@ -1200,101 +1200,6 @@ __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendAr
   }
 }
 
-// ---- the walk on PRECOMPUTED entry records: no staging wave, no barrier, no LDS ------------------------------------------
-// k_walk_records turns every (tile, box) entry of the tile lists into the 16-byte record the walk needs — {position of the
-// tile's first pixel in the box's run, box width (both in bytes unless WIDE), the box as column / row bits of the tile} —
-// once (a PreparedRects keeps them for the forward's and the backward's call).  The walk then needs nothing but the records:
-// every wave loads the 64 records of a round itself (one coalesced 1 KB load, the next round's already in flight), finds the
-// entries that reach its four pixel rows with one ballot, and hands a listed record to its lanes with three v_readlane —
-// the per-lane arithmetic takes them as scalar operands.  The staged form above spends two DEPENDENT global loads per round
-// (tile list -> boxes) in one wave while the other three wait at a barrier.
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_walk_records(const BlendArgs a, const int* __restrict__ box_off, int4* __restrict__ rec,
-                                                      int n_tiles) {
-  const int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-  const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
-  constexpr int kUnit = WIDE ? 1 : 4;
-  const int first = a.tile_start[tile], last = a.tile_start[tile + 1];
-  for (int j = first + (int)threadIdx.x; j < last; j += 256) {
-    const i64 g = a.tile_list[j];
-    Box b;
-    load_box(a.start, a.end, g, a.W, a.H, b);
-    const int wd = b.x1 - b.x0 + 1;
-    const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
-    const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
-    const unsigned cm = (c1 >= c0) ? ((2u << c1) - (1u << c0)) : 0u;
-    const unsigned rm = (r1 >= r0 && cm) ? ((2u << r1) - (1u << r0)) : 0u;
-    const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 - b.x0);
-    rec[j] = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, (int)(cm | (rm << 16)), 0);
-  }
-}
-
-template <int MODE, bool WIDE>
-__device__ __forceinline__ void walk_load_r(WalkBatch& b, unsigned long long& hits, const int4& cur, unsigned lane_bits, int ly, int lxo,
-                                            const float* __restrict__ x) {
-#pragma unroll
-  for (int u = 0; u < kWalkBatch; ++u) {
-    int k;  // scalar: the next set bit, -1 when none is left
-    if (MODE == 2) {
-      k = hits ? 63 - __builtin_clzll(hits) : -1;
-      hits &= ~(1ull << (k & 63));
-    } else {
-      k = hits ? __builtin_ctzll(hits) : -1;
-      hits &= hits - 1ull;
-    }
-    const int ex = __builtin_amdgcn_readlane(cur.x, k & 63), ey = __builtin_amdgcn_readlane(cur.y, k & 63);
-    const unsigned ez = k < 0 ? 0u : (unsigned)__builtin_amdgcn_readlane(cur.z, k & 63);  // no bits: the slot past the last hit
-    b.in[u] = (ez & lane_bits) == lane_bits;
-    const unsigned o = (unsigned)ex + (unsigned)lxo + __umul24((unsigned)ly, (unsigned)ey);
-    b.off[u] = b.in[u] ? o : 0u;
-    b.v[u] = WIDE ? x[b.off[u]] : *(const float*)((const char*)x + b.off[u]);
-  }
-}
-
-template <int MODE, bool WIDE, int OUT>
-__global__ __launch_bounds__(256) void k_pairs_walk_records(const BlendArgs a, const int4* __restrict__ rec, const float* __restrict__ x,
-                                                            float* __restrict__ out, int* __restrict__ dropped,
-                                                            unsigned char* __restrict__ keep, int n_tiles, int xcd_remap) {
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);  // XCD x takes the x-th contiguous eighth of the tiles
-  if (tile < 0) return;
-  constexpr int kUnit = WIDE ? 1 : 4;
-  const int lxo = (lane & 15) * kUnit, ly = w * 4 + (lane >> 4);
-  const unsigned lane_bits = (1u << (lane & 15)) | (1u << (16 + ly));
-  const int first = a.tile_start[tile], n = a.tile_start[tile + 1] - first;
-  if (n <= 0) return;
-  const int nrounds = (n + kWalkStage - 1) / kWalkStage;
-  float acc = (MODE == 0) ? 1.0f : 0.0f;
-  // the records of the first round; every later round's are loaded one round ahead (an index past the list is clamped into
-  // it: straight-line loads, the value is never used)
-  int4 nxt = rec[first + min(((MODE == 2) ? (nrounds - 1) : 0) * kWalkStage + lane, n - 1)];
-  for (int q0 = 0; q0 < nrounds; ++q0) {
-    const int q = (MODE == 2) ? (nrounds - 1 - q0) : q0;
-    const int cnt = min(kWalkStage, n - q * kWalkStage);
-    const int4 cur = nxt;
-    {
-      const int qn = (MODE == 2) ? (q - 1) : (q + 1);
-      nxt = rec[first + min(max(qn, 0) * kWalkStage + lane, n - 1)];
-    }
-    const unsigned rm = (unsigned)cur.z >> 16;
-    unsigned long long hits = __ballot(lane < cnt && ((rm >> (4 * w)) & 0xfu) != 0u);
-    if (hits) {
-      WalkBatch A, B;
-      walk_load_r<MODE, WIDE>(A, hits, cur, lane_bits, ly, lxo, x);
-      for (;;) {
-        if (!hits) { walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep); break; }
-        walk_load_r<MODE, WIDE>(B, hits, cur, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
-        if (!hits) { walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
-        walk_load_r<MODE, WIDE>(A, hits, cur, lane_bits, ly, lxo, x);
-        walk_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
-      }
-    }
-  }
-}
-
 // Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
 // _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
 // One thread per pair; the owning Gaussian is found by bisection in the box offsets.
@@ -1981,33 +1886,8 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(kWalkThreads);
-#ifndef GCP_WALK_RECORDS
-#define GCP_WALK_RECORDS 0  // measurement builds: 1 = the walk on precomputed entry records (internal scratch: not for production)
-#endif
-#if GCP_WALK_RECORDS
-  static void* rec_buf = nullptr;
-  static size_t rec_cap = 0;
-  int K_host = 0;
-  GCP_HIP(hipMemcpyAsync(&K_host, tile_start + n_tiles, sizeof(int), hipMemcpyDeviceToHost, stream));
-  GCP_HIP(hipStreamSynchronize(stream));
-  if ((size_t)K_host * 16 > rec_cap) {
-    if (rec_buf) (void)hipFree(rec_buf);
-    rec_cap = (size_t)K_host * 16 * 2 + 4096;
-    GCP_HIP(hipMalloc(&rec_buf, rec_cap));
-  }
-  static const int rec_every = [] { const char* e = getenv("GCP_WALK_RECORDS_EVERY_CALL"); return (e && *e) ? atoi(e) : 1; }();
-  static const void* rec_for = nullptr;
-  if (rec_every || rec_for != (const void*)tile_list) {
-    if (wide) hipLaunchKernelGGL((k_walk_records<true>), dim3((unsigned)n_tiles), block, 0, stream, a, box_off, (int4*)rec_buf, n_tiles);
-    else hipLaunchKernelGGL((k_walk_records<false>), dim3((unsigned)n_tiles), block, 0, stream, a, box_off, (int4*)rec_buf, n_tiles);
-    rec_for = tile_list;
-  }
-#define GCP_WALK(M, W_, O_) \
-  hipLaunchKernelGGL((k_pairs_walk_records<M, W_, O_>), grid, block, 0, stream, a, (const int4*)rec_buf, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
-#else
 #define GCP_WALK(M, W_, O_) \
   hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, O_>), grid, block, 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
-#endif
 #define GCP_WALK_OUT(M, W_)                                  \
   do {                                                       \
     if (out_mode == kWalkFinal) GCP_WALK(M, W_, kWalkFinal); \

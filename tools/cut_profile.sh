@@ -1,7 +1,9 @@
+# Per-kernel times of the rect cut (rocprofv3 --kernel-trace --stats over tools/cut_diag.py): the one-call cut and the step-by-step one.
+#   gpurun -- bash tools/cut_profile.sh
 set -e
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-O=gpurun_out/r4
+O=gpurun_out/cut_profile
 mkdir -p $O
 for mode in one step; do
   rm -rf $O/cut_$mode
@@ -10,7 +12,7 @@ for mode in one step; do
   python3 - $mode <<'PY'
 import csv, glob, sys
 mode = sys.argv[1]
-for f in glob.glob(f"gpurun_out/r4/cut_{mode}/**/*kernel_stats.csv", recursive=True):
+for f in glob.glob(f"gpurun_out/cut_profile/cut_{mode}/**/*kernel_stats.csv", recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if int(r["Calls"]) >= 10 and "at::native" not in r["Name"]]
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     tot = 0.0

@@ -221,19 +221,21 @@ def function_kernels(src, tag, out):
 
 WRAPPER_KERNELS = [  # (name fragment, label, algorithmic bytes per pair, route)
     ("k_rect_rows_local", "rect list -> rows: flags, per-tile row records, coordinate range (reads the rects once)", 8, "auto"),
-    ("k_rect_rows_gather", "rows: records to their final places", 0.6, "auto"),
-    ("k_rows_rectangles<false>", "rows -> rectangles: count", 0.3, "auto"),
-    ("k_rows_rectangles<true>", "rows -> rectangles: write", 0.3, "auto"),
+    ("k_rect_rows_gather", "rows: records to their final places (kept packed: 8 B per row)", 0.6, "auto"),
+    ("k_rows_rectangles<false, true>", "rows -> rectangles: count (16 rows per thread, straight-line loads)", 0.3, "auto"),
+    ("k_rows_rectangles<true, true>", "rows -> rectangles: write", 0.3, "auto"),
+    ("k_rectangle_boxes", "rectangles -> boxes, offsets, tiles per box (the binning's counting pass)", 0.2, "auto"),
     ("k_sort_hist2<true>", "sort pass 0: histogram (reads the rects)", 8, "rects"),
     ("k_sort_scatter2<true, true>", "sort pass 0: scatter (rects -> key + index)", 16, "rects"),
     ("k_sort_hist2<false>", "sort passes 1, 2: histogram (per pass)", 4, "rects"),
     ("k_sort_scatter2<false, false>", "sort passes 1, 2: scatter (per pass)", 16, "rects"),
     ("gcp_scan_main<0, true, false, true", "indexed scan, cumprod (gather + scan + un-sort)", 16, "rects"),
     ("gcp_scan_main<3, true, false, true", "indexed scan, suffix sum (grad_cumsum)", 16, "rects"),
-    ("k_compact<true, false>", "compaction: count pass (sort route only: the walk counts the zeros it writes)", 4, "rects"),
-    ("k_compact<true, true>", "compaction: write pass (mask + kept values)", 13, "both"),
-    ("k_pairs_scan_boxes<0, false, true>", "tile-list walk, cumprod (counts the zeros it writes)", 8, "boxes"),
-    ("k_pairs_scan_boxes<2, false, true>", "tile-list walk, suffix sum (counts the zeros it writes)", 8, "boxes"),
+    ("k_compact<true, false>", "compaction: count pass (sort route only)", 4, "rects"),
+    ("k_compact<true, true>", "compaction: write pass (mask + kept values; sort route only)", 13, "rects"),
+    ("k_pairs_scan_boxes<0, false, 2>", "tile-list walk, cumprod: writes FINAL values (inclusive / self) + clears the mask bytes of dropped pairs", 8, "boxes"),
+    ("k_pairs_scan_boxes<2, false, 2>", "tile-list walk, suffix sum: writes FINAL values (inclusive - self) + mask", 8, "boxes"),
+    ("k_compact_kept", "kept values moved together (only when the walk dropped something)", 9, "boxes"),
 ]
 
 
@@ -255,8 +257,8 @@ def wrappers(src, tag, out):
     write = {k: sum(v) / len(v) for k, v in per_launch(os.path.join(src, "wr_write"), "WRITE_SIZE", pick).items()}
     lines = [f"# {tag}: rows a5 / a6 — create_alpha_brend / grad_cumsum (gs_model.py:544-566, :716-722) at the cfg3 scene, M = {m} pairs", "",
              "`rocprofv3 --kernel-trace --stats` of `python3 tools/wrapper_bench.py cfg3 --profile` (create_alpha_brend(rects) and "
-             "grad_cumsum(rects) by the default route — the list cut into boxes and walked — and by the general sort route, "
-             "create_alpha_brend_boxes, grad_cumsum_boxes, 4 times each) and separate `--pmc FETCH_SIZE` / `--pmc "
+             "grad_cumsum(rects) by the default route — the list cut into boxes (one call, one read-back) and walked, the walk "
+             "writing the final values and the mask — and by the general sort route, create_alpha_brend_boxes, grad_cumsum_boxes, 4 times each) and separate `--pmc FETCH_SIZE` / `--pmc "
              "WRITE_SIZE` passes of the same command.  HBM bytes = 2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950 "
              "correction of the guide; FETCH_SIZE halves only wide streaming reads, so for the gather / scatter kernels the figure "
              "is an upper bound).", "",

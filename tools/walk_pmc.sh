@@ -14,7 +14,7 @@ for p in ("p1","p2","p3"):
     for f in glob.glob(f"gpurun_out/walk_pmc/{p}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(f)):
-            if "k_pairs_scan_boxes<0, false, true>" in r["Kernel_Name"]:
+            if "k_pairs_scan_boxes<0, false, 1>" in r["Kernel_Name"]:
                 a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
         # several rows per dispatch (one per counter); count dispatches from any counter
         for k, (v, n) in acc.items():

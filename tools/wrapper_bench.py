@@ -110,11 +110,20 @@ def main():
             bins = raster.bin_tiles(sc["start"], sc["end"], w, h)
             st["boxes_box_offsets_ms"] = timeit(lambda: raster.box_offsets(sc["start"], sc["end"], w, h), iters)
             boff = raster.box_offsets(sc["start"], sc["end"], w, h)
-            st["boxes_walk_cumprod_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True), iters)
-            st["boxes_walk_reverse_ms"] = timeit(lambda: raster.scan_boxes(bins, sc["start"], sc["end"], boff, grad, 2, count_dropped=True), iters)
-            incl_b, dropped = raster.scan_boxes(bins, sc["start"], sc["end"], boff, anti, 0, count_dropped=True)
-            st["boxes_compact_finish_ms"] = timeit(lambda: raster.compact_finish(incl_b, anti, 0, dropped=dropped), iters)
-            del incl_b, dropped
+            st["boxes_walk_cumprod_ms"] = timeit(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, anti, 0), iters)
+            st["boxes_walk_reverse_ms"] = timeit(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, grad, 2), iters)
+            fin_b, keep_b, dropped = raster.finish_boxes(bins, sc["start"], sc["end"], boff, anti, 0)
+            st["boxes_kept_count_ms"] = timeit(lambda: raster.compact_kept(fin_b, keep_b, dropped), iters)
+            st["boxes_dropped_pairs"] = int(m - raster.compact_kept(fin_b, keep_b, dropped)[0].numel())
+            del fin_b, keep_b, dropped
+            # the cut of the default route and its binning (the counting pass is the cut's)
+            st["one_call_cut_ms"] = timeit(lambda: raster.rects_to_boxes(rects), iters)
+            st["step_by_step_cut_ms"] = timeit(lambda: raster.rects_to_boxes(rects, one_call=False), iters)
+            rb = raster.rects_to_boxes(rects)
+            if rb is not None:
+                st["bin_after_cut_ms"] = timeit(lambda: rb.bin(), iters)
+                st["rectangles"] = int(rb.start.size(0))
+            del rb
             st["tile_entries"] = bins.n_tile_pairs
             del bins, boff
             y = torch.empty_like(anti)

@@ -852,3 +852,59 @@ def test_one_call_cut_with_carry_rows_and_on_lists_it_has_no_room_for(device):
     neg[17, 1] = -4
     with pytest.raises(RuntimeError, match="negative"):
         raster._cut_rects_once(neg, False, 0, 0, 8)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_default_route_on_random_box_lists(device, seed):
+    """Seeded fuzz of the whole default route (one-call cut with its slot / pool / carry-tile layout, binning from the cut's
+    counts, the final-value walk, the kept count and the compaction that is left) against the literal CPU statement: random
+    boxes — one-pixel-wide ones, single pixels, boxes that touch or repeat — in lists from a few pairs to several scan tiles,
+    int32 and int64, with and without the carry rows of a chunked call (a random subset of pixels in torch.unique's order; in
+    front for `_create_alpha_brend`, at the end for `grad_cumsum`), values with exact zeros.  Masks bit-exact, transmittance
+    within 1e-5 absolute."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator().manual_seed(1000 + seed)
+    w, h = [(40, 30), (199, 149), (63, 300), (500, 11)][seed % 4]
+    n_boxes = int(torch.randint(1, [4, 60, 400, 1500][(seed // 4) % 4] + 1, (1,), generator=g))
+    max_half = [0, 1, 4, 12, 30][seed % 5]
+    cx = torch.randint(0, w + 1, (n_boxes,), generator=g)
+    cy = torch.randint(0, h + 1, (n_boxes,), generator=g)
+    hx = torch.randint(0, max_half + 1, (n_boxes,), generator=g)
+    hy = torch.randint(0, max_half + 1, (n_boxes,), generator=g)
+    if seed % 3 == 0:
+        hx[::2] = 0  # one-pixel-wide columns among the boxes
+    start = torch.stack([(cx - hx).clamp(min=0), (cy - hy).clamp(min=0)], 1).to(torch.int32)
+    end = torch.stack([(cx + hx).clamp(max=w), (cy + hy).clamp(max=h)], 1).to(torch.int32)
+    if seed % 5 == 1 and n_boxes > 2:
+        start[1], end[1] = start[0], end[0]  # the same box twice in a row
+    rects = raster.expand_rects(start.to(device), end.to(device), w, h)
+    m = rects.size(0)
+    carry = seed % 2 == 1
+    c = 0
+    if carry:
+        pix = torch.unique(torch.stack([torch.randint(0, w + 1, (m // 3 + 5,), generator=g), torch.randint(0, h + 1, (m // 3 + 5,), generator=g)], 1), dim=0)
+        c = pix.size(0)
+    for flag in ("cumprod", "cumsum", "grad_cumsum"):
+        if carry:
+            lst = torch.cat([rects, pix.to(torch.int32).to(device)] if flag == "grad_cumsum" else [pix.to(torch.int32).to(device), rects]).contiguous()
+        else:
+            lst = rects
+        n = lst.size(0)
+        vals = (1.0 - 0.95 * torch.rand(n, generator=g)) if flag != "grad_cumsum" else torch.randint(-2, 3, (n,), generator=g).float()
+        vals[torch.randint(0, n, (n // 9 + 1,), generator=g)] = 0.0
+        cut = c if carry else None
+        for lst_dev in ((lst, lst.long()) if seed % 6 == 2 else (lst,)):
+            if flag == "grad_cumsum":
+                v, k = ck.grad_cumsum(lst_dev, vals.to(device), cut)
+                wv, wk_flipped = ow.grad_cumsum(lst.cpu(), vals, cut)
+                wk = wk_flipped.flip(0)
+            else:
+                v, k = ck.create_alpha_brend(lst_dev, vals.to(device), flag, cut)
+                wv, wk, _, _ = ow.create_alpha_brend(lst.cpu(), vals, flag, cut)
+            assert torch.equal(k.cpu(), wk), (seed, flag)
+            assert v.numel() == wv.numel()
+            tol = dict(atol=TOL, rtol=0) if flag == "cumprod" else dict(atol=1e-4, rtol=TOL)
+            torch.testing.assert_close(v.cpu(), wv, **tol)

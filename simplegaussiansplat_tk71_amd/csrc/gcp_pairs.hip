@@ -131,51 +131,53 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   unsigned m[kRowsPerThread];
   int mx = 0, my = 0, mn = 0x7fffffff;
   const bool vec = (((uintptr_t)rects) & 15u) == 0;
-  int2 before[kRowsPerThread];  // I64: the element in front of each row of the lane (lane 0), fetched with the row loads
-  if (I64 && (tile + 1) * kElemTile <= n) {
-    // every tile but the last, straight-line: all sixteen 16-byte loads of the lane are issued before anything waits
-    // (behind a bounds test per element the compiler waits row by row: 0.88 -> 0.76 ms for the whole cut at cfg3; the
-    // int32 form, two loads per row behind one test, measured no faster this way)
+  int2 before[kRowsPerThread];  // the element in front of each row of the wave (what its lane 0 compares with), fetched with the row loads
+  const bool full = (tile + 1) * kElemTile <= n;  // block-uniform: every tile but the last
+  if (full) {
+    // straight-line: all loads of the lane — its sixteen elements and, at a wave-uniform address (one broadcast line), the
+    // element in front of each of its rows — are issued before anything waits.  (Behind a bounds test per element, or with
+    // lane 0 fetching its neighbour inside the compare loop, the compiler waits load by load: gfx950 counts loads in one
+    // in-order counter and cannot know how many a branch issued.)
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) e[r][k] = rect_at<true>(rects, base + r * 256 + lane * 4 + k);
-      const i64 p = base + r * 256;
-      before[r] = (lane == 0 && p > 0) ? rect_at<true>(rects, p - 1) : make_int2(0x7ffffff0, 0x7ffffff0);
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < kRowsPerThread; ++r) {  // all loads of the lane first: 16-byte loads where the row is whole
       const i64 p = base + r * 256 + lane * 4;
-      if (!I64 && vec && p + 3 < n) {
+      if (I64) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[r][k] = rect_at<true>(rects, p + k);
+      } else if (vec) {
         const int4 a = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(rects) + p);
         const int4 b = *reinterpret_cast<const int4*>(reinterpret_cast<const int2*>(rects) + p + 2);
         e[r][0] = make_int2(a.x, a.y); e[r][1] = make_int2(a.z, a.w); e[r][2] = make_int2(b.x, b.y); e[r][3] = make_int2(b.z, b.w);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[r][k] = (p + k < n) ? rect_at<I64>(rects, p + k) : make_int2(0x7ffffff0, 0x7ffffff0);
+        for (int k = 0; k < 4; ++k) e[r][k] = rect_at<false>(rects, p + k);
       }
-      if (I64) {
-        const i64 p0 = base + r * 256;
-        before[r] = (lane == 0 && p0 > 0 && p0 <= n) ? rect_at<true>(rects, p0 - 1) : make_int2(0x7ffffff0, 0x7ffffff0);
-      }
+      const i64 p0 = base + r * 256;
+      const int2 q = rect_at<I64>(rects, p0 > 0 ? p0 - 1 : 0);
+      before[r] = p0 > 0 ? q : make_int2(0x7ffffff0, 0x7ffffff0);  // (nothing continues the first element of the list)
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const i64 p = base + r * 256 + lane * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[r][k] = (p + k < n) ? rect_at<I64>(rects, p + k) : make_int2(0x7ffffff0, 0x7ffffff0);
+      const i64 p0 = base + r * 256;
+      before[r] = (p0 > 0 && p0 <= n) ? rect_at<I64>(rects, p0 - 1) : make_int2(0x7ffffff0, 0x7ffffff0);
     }
   }
 #pragma unroll
   for (int r = 0; r < kRowsPerThread; ++r) {
     const i64 p = base + r * 256 + lane * 4;
-    // the element in front of the lane's four: the left neighbour's last one; lane 0 of a row fetches it
+    // the element in front of the lane's four: the left neighbour's last one; lane 0 of a row takes the fetched one
     int2 prev;
     prev.x = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].x);
     prev.y = dpp_i<0x138, 0xf>(0x7ffffff0, e[r][3].y);
-    if (lane == 0) {  // (nothing continues the first element of the list)
-      if (I64) prev = before[r];
-      else prev = (p > 0 && p <= n) ? rect_at<false>(rects, p - 1) : make_int2(0x7ffffff0, 0x7ffffff0);
-    }
+    if (lane == 0) prev = before[r];
     m[r] = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (p + k < n) {
+      if (full || p + k < n) {
         const bool cont = e[r][k].x == prev.x + 1 && e[r][k].y == prev.y;
         m[r] |= (cont ? 0u : 1u) << k;
         prev = e[r][k];

@@ -84,11 +84,16 @@ CASES = {
 }
 
 
-def _worker(rank, world, port, case, exact, out_dir):
+def _worker(rank, world, port, case, exact, out_dir, backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: the ranks share GPU 0 (the test box has one); nccl = RCCL over xGMI: one GPU per rank, as bench.py runs
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device("cuda", 0)
         key, x, inv, inv_len, go = _pair_list(CASES[case](), exact, seed=11)
         shards = sharding.partition_groups(inv_len, world)
         s = shards[rank]
@@ -147,6 +152,23 @@ def test_sharded_hip_scans_equal_the_single_rank_frame(device, tmp_path, case, w
     rows = torch.cat([_group_rows(g["y"], g["gin"], sharding.local_arrays(s, key, x, inv, inv_len)[3]) for s, g in zip(shards, got)])
     assert torch.equal(got[0]["frame_rows"], rows)
     assert all(g["frame_rows"] is None for g in got[1:])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_hip_scans_over_rccl(device, tmp_path, world):
+    """The same on RCCL — one GPU per rank, the rows gathered and scattered GPU to GPU over xGMI — wherever the node has the
+    GPUs (skipped on a one-GPU box; the driver's scaling run is the first place with more)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this node shows {torch.cuda.device_count()}")
+    case = "long_groups_at_the_cut"
+    mp.spawn(_worker, args=(world, _free_port(), case, True, str(tmp_path), "nccl"), nprocs=world, join=True)
+    got = [torch.load(str(tmp_path / f"rank{r}.pt")) for r in range(world)]
+    key, x, inv, inv_len, go = _pair_list(CASES[case](), True, seed=11)
+    y1, gin1, suf1 = (t.cpu() for t in _scan_slice(device, key, x, inv, inv_len, go))
+    assert torch.equal(torch.cat([g["y"] for g in got]), y1) and torch.equal(torch.cat([g["gin"] for g in got]), gin1)
+    assert torch.equal(torch.cat([g["suf"] for g in got]), suf1)
+    assert torch.equal(got[0]["frame_rows"], _group_rows(y1, gin1, inv_len))
 
 
 @pytest.mark.timeout(900)

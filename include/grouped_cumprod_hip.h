@@ -325,13 +325,18 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
  * — the fp32 operation gcp_compact_finish would apply to the stored inclusive value: the same bits — and
  *   keep[pair]   = (inclusive != 0)                                  (gs_model.py:560, :575-578)
  * as one byte per pair (the call sets every byte to 1 and the walk clears the bytes of the pairs it drops);
- * dropped_per_tile (required, int32[ceil(n_pairs / 4096)]) counts them per 4096 consecutive pairs.  When
+ * dropped_per_tile (required, int32[ceil(n_pairs / 4096)]) counts them per 4096 consecutive pairs.  prepared != 0: the
+ * caller has already run gcp_pairs_finish_prepare(keep, dropped_per_tile, n_pairs, stream) on the same stream — the two
+ * fills, which depend on nothing but n_pairs, can then be queued BEFORE the host waits for gcp_rects_cut's info8 and run
+ * while it does.  When
  * gcp_compact_kept_count reports that everything was kept, `values` and `keep` ARE the result of _create_alpha_brend
  * (8 B per pair + the 1 B fill of the mask instead of 21); otherwise gcp_compact_kept_write moves the kept values together
  * (5 B read + 4 B written per pair). */
+int gcp_pairs_finish_prepare(uint8_t* keep, int32_t* dropped_per_tile, int64_t n_pairs, void* stream);
 int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                            const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream);
+                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, int32_t prepared,
+                           void* stream);
 
 /* The stream compaction that remains after gcp_pairs_finish_boxes, split at the one device->host read that sizes the result
  * (the reference's `output[mask]`, gs_model.py:575-578, synchronises likewise):

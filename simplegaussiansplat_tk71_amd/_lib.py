@@ -79,7 +79,8 @@ SIGNATURES = {
     "gcp_rects_key_range": (ctypes.c_int, [_c_void_p, _i64, _c_void_p, _c_void_p]),
     "gcp_compact_workspace_bytes": (_sz, [_i64]),
     "gcp_compact_finish": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i32, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),
-    "gcp_pairs_finish_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 6 + [_i64, _i32, _c_void_p, _c_void_p]),
+    "gcp_pairs_finish_prepare": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _c_void_p]),
+    "gcp_pairs_finish_boxes": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i32, _i32] + [_c_void_p] * 6 + [_i64, _i32, _c_void_p, _i32, _c_void_p]),
     "gcp_compact_kept_workspace_bytes": (_sz, [_i64]),
     "gcp_compact_kept_count": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _i64, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_compact_kept_write": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _c_void_p, _c_void_p, _sz, _c_void_p]),

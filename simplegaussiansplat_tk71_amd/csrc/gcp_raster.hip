@@ -1863,15 +1863,15 @@ int gcp_compact_finish(const float* inclusive, const float* self, int64_t begin,
 // keep != NULL: the FINAL form (values + keep mask + zero counts); else the inclusive form, counting when `dropped_per_tile`
 static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                      const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x, float* out,
-                     int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, uint8_t* keep, void* stream_) {
+                     int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, uint8_t* keep, void* stream_, bool prepared = false) {
   hipStream_t stream = (hipStream_t)stream_;
   BlendArgs a;
   const int st = make_args(a, start_xy, end_xy, nullptr, nullptr, nullptr, nullptr, width, height, tile_start, tile_list);
   if (st != GCP_OK || n_gauss < 0 || mode < 0 || mode > 2 || n_pairs < 0 || n_pairs > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
   if (keep && !dropped_per_tile && n_pairs > 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n_pairs == 0) return GCP_OK;
-  if (keep) GCP_HIP(hipMemsetAsync(keep, 1, (size_t)n_pairs, stream));  // every pair kept until the walk finds its inclusive value 0
-  if (dropped_per_tile)
+  if (keep && !prepared) GCP_HIP(hipMemsetAsync(keep, 1, (size_t)n_pairs, stream));  // every pair kept until the walk finds its inclusive value 0
+  if (dropped_per_tile && !prepared)
     GCP_HIP(hipMemsetAsync(dropped_per_tile, 0, (size_t)((n_pairs + kCompactTile - 1) / kCompactTile) * sizeof(int), stream));
   if (n_gauss == 0) return GCP_OK;
   if (!start_xy || !end_xy || !tile_list || !box_off || !x || !out || x == out) return GCP_ERR_INVALID_ARGUMENT;
@@ -1913,12 +1913,23 @@ int gcp_pairs_scan_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t
                    dropped_per_tile, nullptr, stream);
 }
 
+int gcp_pairs_finish_prepare(uint8_t* keep, int32_t* dropped_per_tile, int64_t n_pairs, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_pairs < 0 || n_pairs > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
+  if (n_pairs == 0) return GCP_OK;
+  if (!keep || !dropped_per_tile) return GCP_ERR_INVALID_ARGUMENT;
+  GCP_HIP(hipMemsetAsync(keep, 1, (size_t)n_pairs, stream));
+  GCP_HIP(hipMemsetAsync(dropped_per_tile, 0, (size_t)((n_pairs + kCompactTile - 1) / kCompactTile) * sizeof(int), stream));
+  return GCP_OK;
+}
+
 int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64_t n_gauss, int32_t width, int32_t height,
                            const int32_t* tile_start, const int32_t* tile_list, const int32_t* box_off, const float* x,
-                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, void* stream) {
+                           float* values, uint8_t* keep, int64_t n_pairs, int32_t mode, int32_t* dropped_per_tile, int32_t prepared,
+                           void* stream) {
   if (n_pairs > 0 && (!keep || !dropped_per_tile)) return GCP_ERR_INVALID_ARGUMENT;
   return walk_impl(start_xy, end_xy, n_gauss, width, height, tile_start, tile_list, box_off, x, values, n_pairs, mode,
-                   dropped_per_tile, keep, stream);
+                   dropped_per_tile, keep, stream, prepared != 0);
 }
 
 size_t gcp_compact_kept_workspace_bytes(int64_t n) { return gcp_compact_workspace_bytes(n); }

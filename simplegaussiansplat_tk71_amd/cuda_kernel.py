@@ -329,19 +329,21 @@ def _rects_as_boxes(rects, values, flag, cutting_number=None):
     """The boxes route from nothing but the rect list; None if the list is not a concatenation of boxes."""
     if flag not in ("cumprod", "cumsum", "cumsum_reverse"):
         raise ValueError(flag)
+    values = values.detach().contiguous()
+    n = values.numel()
+    if n != int(rects.shape[0]):
+        raise RuntimeError(f"values: {n} rows, rects has {int(rects.shape[0])}")
+    # the walk's output buffers and their two fills are queued BEFORE the cut: they run while the host waits for its read-back
+    buffers = _raster.finish_buffers(values) if (values.is_cuda and values.dtype == torch.float32 and n) else None
     prep = rects if isinstance(rects, PreparedRects) else PreparedRects(rects, carry_rows=int(cutting_number) if cutting_number else 0,
                                                                        carry_at_end=flag == "cumsum_reverse")
     rb, bins = prep.boxes, prep.bins
     if rb is None:
         return None
-    values = values.detach().contiguous()
-    n = values.numel()
-    if n != int(prep.shape[0]):
-        raise RuntimeError(f"values: {n} rows, rects has {int(prep.shape[0])}")
-    return _walk_and_finish(bins, rb.start, rb.end, rb.box_off, values, flag, cutting_number)
+    return _walk_and_finish(bins, rb.start, rb.end, rb.box_off, values, flag, cutting_number, buffers)
 
 
-def _walk_and_finish(bins, start, end, box_off, values, flag, cutting_number=None):
+def _walk_and_finish(bins, start, end, box_off, values, flag, cutting_number=None, buffers=None):
     """Walk + tail of _create_alpha_brend (gs_model.py:546-564) from binned boxes.  The walk writes the FINAL values
     (inclusive / self, inclusive - self) and clears the mask byte of every pair whose inclusive value is exactly 0; one
     device->host read of the kept count — the one that sizes the result — decides: nothing dropped (the usual case: a
@@ -355,7 +357,7 @@ def _walk_and_finish(bins, start, end, box_off, values, flag, cutting_number=Non
         if n:
             raise RuntimeError("values: the boxes expand to no pair at all")
         return [values.new_empty(0), torch.zeros(0, dtype=torch.bool, device=values.device)]
-    final, keep, dropped = _raster.finish_boxes(bins, start, end, box_off, values, mode)
+    final, keep, dropped = _raster.finish_boxes(bins, start, end, box_off, values, mode, buffers=buffers)
     values_out, mask = _raster.compact_kept(final, keep, dropped, max(0, min(begin, n)), max(0, stop))
     return [values_out, mask]
 

@@ -325,10 +325,27 @@ def scan_boxes(bins, startpoint, endpoint, box_off, values, mode, count_dropped=
     return (out, dropped) if count_dropped else out
 
 
-def finish_boxes(bins, startpoint, endpoint, box_off, values, mode):
+def finish_buffers(values):
+    """The outputs of `finish_boxes` for `values` (f32[M]), allocated and — the mask set to ones, the zero counts cleared —
+    initialised NOW: nothing of it depends on the boxes, so a caller that still has to wait for the cut's read-back queues the
+    two fills first and they run while the host waits.  -> (final, keep, dropped) to pass as `finish_boxes(..., buffers=)`."""
+    x = _dev_tensor(values, "values", torch.float32)
+    _require(x.dim() == 1, "values: expected a 1-D tensor")
+    m = x.numel()
+    out = torch.empty_like(x)
+    keep = torch.empty(m, dtype=torch.uint8, device=x.device)
+    dropped = torch.empty((m + 4095) // 4096, dtype=torch.int32, device=x.device)
+    if m:
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().gcp_pairs_finish_prepare(keep.data_ptr(), dropped.data_ptr(), m, _stream(x.device)), "gcp_pairs_finish_prepare")
+    return out, keep, dropped
+
+
+def finish_boxes(bins, startpoint, endpoint, box_off, values, mode, buffers=None):
     """The walk of `scan_boxes` writing the FINAL values of _create_alpha_brend (gs_model.py:557-564) instead of the inclusive
     ones: -> (final f32[M] = inclusive / self (mode 0) or inclusive - self (modes 1, 2), keep uint8[M] = inclusive != 0,
-    dropped int32[ceil(M / 4096)]).  Hand all three to `compact_kept`: when nothing was dropped they ARE the result."""
+    dropped int32[ceil(M / 4096)]).  Hand all three to `compact_kept`: when nothing was dropped they ARE the result.
+    buffers: what `finish_buffers(values)` returned on this stream (already initialised)."""
     start = _dev_tensor(startpoint, "startpoint", torch.int32, (2,))
     end = _dev_tensor(endpoint, "endpoint", torch.int32, (2,))
     x = _dev_tensor(values, "values", torch.float32)
@@ -336,16 +353,17 @@ def finish_boxes(bins, startpoint, endpoint, box_off, values, mode):
     _require(x.dim() == 1, "values: expected a 1-D tensor")
     _require(off.numel() >= bins.n_gauss + 1, "box_off: expected n_gauss + 1 offsets")
     m = x.numel()
-    out = torch.empty_like(x)
-    keep = torch.empty(m, dtype=torch.uint8, device=x.device)
-    dropped = torch.empty((m + 4095) // 4096, dtype=torch.int32, device=x.device)
+    prepared = buffers is not None
+    out, keep, dropped = buffers if prepared else (torch.empty_like(x), torch.empty(m, dtype=torch.uint8, device=x.device),
+                                                   torch.empty((m + 4095) // 4096, dtype=torch.int32, device=x.device))
+    _require(out.numel() == m and keep.numel() == m and dropped.numel() == (m + 4095) // 4096, "buffers: not those of finish_buffers(values)")
     if m == 0:
         return out, keep, dropped
     _require(bins.n_tile_pairs > 0, "values: the boxes expand to no pair at all")
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().gcp_pairs_finish_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                                       bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
-                                                      out.data_ptr(), keep.data_ptr(), m, int(mode), dropped.data_ptr(),
+                                                      out.data_ptr(), keep.data_ptr(), m, int(mode), dropped.data_ptr(), 1 if prepared else 0,
                                                       _stream(x.device)), "gcp_pairs_finish_boxes")
     return out, keep, dropped
 

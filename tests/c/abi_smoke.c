@@ -169,7 +169,7 @@ static int run_default_route(void) {
       hipMalloc((void**)&d_fin, N * 4) || hipMalloc((void**)&d_val, N * 4) || hipMalloc((void**)&d_keep, N) || hipMalloc((void**)&d_drop, 4) ||
       hipMalloc((void**)&d_cnt, 4)) return 1;
   CHECK(gcp_bin_tiles_fill(d_s, d_e, n_rects, w, h, d_toff, K, d_tstart, d_tlist, ws_bin, b_bin, NULL));
-  CHECK(gcp_pairs_finish_boxes(d_s, d_e, n_rects, w, h, d_tstart, d_tlist, d_boff, d_a, d_fin, d_keep, N, 0, d_drop, NULL));
+  CHECK(gcp_pairs_finish_boxes(d_s, d_e, n_rects, w, h, d_tstart, d_tlist, d_boff, d_a, d_fin, d_keep, N, 0, d_drop, 0, NULL));
   CHECK(gcp_compact_kept_count(d_keep, d_drop, N, 0, N, d_cnt, ws_cmp, b_cmp, NULL));
   hipDeviceSynchronize();
   int32_t kept = -1; hipMemcpy(&kept, d_cnt, 4, 2);  /* read 2: sizes the result, as the reference's output[mask] does */

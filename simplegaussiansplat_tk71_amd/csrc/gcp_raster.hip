@@ -1200,149 +1200,6 @@ __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendAr
   }
 }
 
-// ---- the DENSE walk: one wave per tile, lanes over the PAIRS of an entry, the pixels' running values in LDS -------------------
-// In the kernel above a lane is a pixel: a (wave, entry) visit costs one load and one store instruction whether 4 or 64 of the
-// wave's 4 x 16 pixels lie in the entry's box — 24 of 64 lanes on average at BASELINE's box sizes, 2.3 visits per entry —
-// and the vector-memory pipe takes a wave instruction at 4 lanes per cycle however many are enabled: the kernel is bound by
-// the NUMBER of its memory instructions.  Here a wave owns a whole 16 x 16 tile and lays its lanes over the pairs of the
-// entry's box inside the tile, row-major (pair i of the clipped region = row i / cw, column i % cw: one multiply by a staged
-// reciprocal): ceil(pairs / 64) instructions per entry, nearly all lanes useful.  The running product / sum of each of the
-// tile's 256 pixels lives in LDS (1 KB per wave); entries are folded strictly in list order by the one wave, so every pixel
-// is still scanned sequentially in depth order (the bits of the kernel above).  No barrier: the four waves of a block walk
-// four neighbouring tiles independently, each staging its own 64 entries per round in registers (records handed to the lanes
-// with v_readlane).
-struct DenseBatch {
-  bool in[kWalkBatch];
-  unsigned off[kWalkBatch];
-  int slot[kWalkBatch];
-  float v[kWalkBatch];
-};
-// scalar cursor over the listed entries of a round and the 64-pair parts of each: (k, it) = part `it` of entry k
-struct DenseCursor {
-  unsigned long long hits;
-  int k, it, nit;
-  __device__ __forceinline__ bool more() const { return hits != 0ull || (k >= 0 && it + 1 < nit); }
-};
-template <int MODE, bool WIDE>
-__device__ __forceinline__ void dense_load(DenseBatch& b, DenseCursor& c, const int4& rec, int lane, const float* __restrict__ x) {
-  constexpr int kUnit = WIDE ? 1 : 4;
-#pragma unroll
-  for (int u = 0; u < kWalkBatch; ++u) {
-    if (c.k >= 0 && c.it + 1 < c.nit) {
-      ++c.it;
-    } else {  // the next listed entry, -1 when none is left
-      if (MODE == 2) {
-        c.k = c.hits ? 63 - __builtin_clzll(c.hits) : -1;
-        c.hits &= ~(1ull << (c.k & 63));
-      } else {
-        c.k = c.hits ? __builtin_ctzll(c.hits) : -1;
-        c.hits &= c.hits - 1ull;
-      }
-      c.it = 0;
-      c.nit = c.k < 0 ? 0 : ((__builtin_amdgcn_readlane(rec.z, c.k & 63) >> 22) & 7);
-    }
-    const int ep = __builtin_amdgcn_readlane(rec.x, c.k & 63), ewd = __builtin_amdgcn_readlane(rec.y, c.k & 63);
-    const int geo = c.k < 0 ? 0 : __builtin_amdgcn_readlane(rec.z, c.k & 63);  // no pairs: the slot past the last part
-    const int inv = __builtin_amdgcn_readlane(rec.w, c.k & 63);
-    const int cw = geo & 31, tot = (geo >> 5) & 511, sbase = (geo >> 14) & 255;
-    const int i = lane + 64 * c.it;
-    const int row = (int)(((unsigned)i * (unsigned)inv) >> 16);  // i / cw, exact for i < 320 and cw <= 16
-    const int col = i - row * cw;
-    b.in[u] = i < tot;
-    const unsigned o = (unsigned)ep + (unsigned)row * (unsigned)ewd + (unsigned)(col * kUnit);
-    b.off[u] = b.in[u] ? o : 0u;
-    b.slot[u] = sbase + row * kTile + col;
-    b.v[u] = WIDE ? x[b.off[u]] : *(const float*)((const char*)x + b.off[u]);
-  }
-}
-template <int MODE, bool WIDE, int OUT>
-__device__ __forceinline__ void dense_fold(const DenseBatch& b, float* __restrict__ out, float* __restrict__ acc_lds,
-                                           int* __restrict__ dropped, unsigned char* __restrict__ keep) {
-#pragma unroll
-  for (int u = 0; u < kWalkBatch; ++u) {
-    bool drop = false;
-    if (b.in[u]) {
-      float acc = acc_lds[b.slot[u]];
-      acc = (MODE == 0) ? acc * b.v[u] : acc + b.v[u];
-      acc_lds[b.slot[u]] = acc;
-      drop = acc == 0.0f;  // NaN is kept, as `!= 0` keeps it
-      const float res = (OUT != kWalkFinal) ? acc : (MODE == 0 ? acc / b.v[u] : acc - b.v[u]);
-      if (WIDE) out[b.off[u]] = res;
-      else *(float*)((char*)out + b.off[u]) = res;
-    }
-    if (OUT != kWalkInclusive) {
-      if (OUT == kWalkFinal && __ballot(drop) != 0ull) {
-        if (drop) keep[WIDE ? b.off[u] : (b.off[u] >> 2)] = 0;
-      }
-      walk_count_dropped<WIDE>(drop, b.off[u], dropped);
-    }
-  }
-}
-
-template <int MODE, bool WIDE, int OUT>
-__global__ __launch_bounds__(256) void k_pairs_walk_dense(const BlendArgs a, const int* __restrict__ box_off, const float* __restrict__ x,
-                                                          float* __restrict__ out, int* __restrict__ dropped,
-                                                          unsigned char* __restrict__ keep, int n_tiles, int n_blocks, int xcd_remap) {
-  __shared__ float s_acc[4][kTile * kTile];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // XCD x takes the x-th contiguous eighth of the blocks (= a band of tile rows): a box's pieces mostly share an L2
-  const int chunk = (int)sort_chunk(blockIdx.x, n_blocks, xcd_remap);
-  if (chunk < 0) return;
-  const int tile = 4 * chunk + w;
-  if (tile >= n_tiles) return;
-  const int first = a.tile_start[tile], n = a.tile_start[tile + 1] - first;
-  if (n <= 0) return;
-  float* const acc = s_acc[w];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[lane + 64 * j] = (MODE == 0) ? 1.0f : 0.0f;
-  const int tile_x0 = (tile % a.tiles_x) * kTile, tile_y0 = (tile / a.tiles_x) * kTile;
-  constexpr int kUnit = WIDE ? 1 : 4;
-  const int nrounds = (n + kWalkStage - 1) / kWalkStage;
-  for (int q0 = 0; q0 < nrounds; ++q0) {
-    const int q = (MODE == 2) ? (nrounds - 1 - q0) : q0;
-    const int base = first + q * kWalkStage;
-    const int cnt = min(kWalkStage, first + n - base);
-    // this wave's own staging: lane j turns entry j of the round into {first pair of the box inside the tile, box width (both
-    // in bytes unless WIDE), cw | pairs << 5 | first pixel slot << 14 | parts << 22, 65536 / cw rounded up}
-    int4 rec = make_int4(0, 0, 0, 0);
-    bool valid = false;
-    if (lane < cnt) {
-      const i64 g = a.tile_list[base + lane];
-      Box b;
-      load_box(a.start, a.end, g, a.W, a.H, b);
-      const int wd = b.x1 - b.x0 + 1;
-      const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTile - 1);
-      const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTile - 1);
-      const int cw = c1 - c0 + 1, ch = r1 - r0 + 1;
-      valid = cw > 0 && ch > 0;
-      if (valid) {
-        // (modulo 2^32: every pair of the list lies below 2^32 bytes, 2^31 pairs when WIDE)
-        const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 + r0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 + c0 - b.x0);
-        const int tot = cw * ch;
-        rec = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, cw | (tot << 5) | ((r0 * kTile + c0) << 14) | (((tot + 63) >> 6) << 22),
-                        (int)(65535u / (unsigned)cw + 1u));
-      }
-    }
-    DenseCursor c;
-    c.hits = __ballot(valid);
-    c.k = -1; c.it = 0; c.nit = 0;
-    // two batches in flight, as above: the loads of the next one are issued before the stores of the one in hand
-    if (c.hits) {
-      DenseBatch A, B;
-      dense_load<MODE, WIDE>(A, c, rec, lane, x);
-      for (;;) {
-        if (!c.more()) { dense_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep); break; }
-        dense_load<MODE, WIDE>(B, c, rec, lane, x);
-        dense_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
-        if (!c.more()) { dense_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
-        dense_load<MODE, WIDE>(A, c, rec, lane, x);
-        dense_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
-      }
-    }
-  }
-}
-
 // Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
 // _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
 // One thread per pair; the owning Gaussian is found by bisection in the box offsets.
@@ -2029,18 +1886,8 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(kWalkThreads);
-#ifndef GCP_WALK_DENSE
-#define GCP_WALK_DENSE 0
-#endif
-#if GCP_WALK_DENSE
-  const int n_blocks = (n_tiles + 3) / 4;
-  const dim3 dgrid(sort_grid(n_blocks, xcd_remap));
-#define GCP_WALK(M, W_, O_) \
-  hipLaunchKernelGGL((k_pairs_walk_dense<M, W_, O_>), dgrid, dim3(256), 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, n_blocks, xcd_remap)
-#else
 #define GCP_WALK(M, W_, O_) \
   hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, O_>), grid, block, 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
-#endif
 #define GCP_WALK_OUT(M, W_)                                  \
   do {                                                       \
     if (out_mode == kWalkFinal) GCP_WALK(M, W_, kWalkFinal); \

@@ -688,3 +688,21 @@ def test_bare_capture_of_the_function_refuses_leaves_of_eager_steps(device, tmp_
     res = subprocess.run([sys.executable, "-X", "faulthandler", str(script), root, mode], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert ("RAISED True" if mode == "stale" else "CAPTURED True") in res.stdout, res.stdout + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 1024, 1025, 4099, 40610, 65535, 65536, 65537, 200001])
+def test_exclusive_scan_i32_every_size_class(device, n):
+    """The int32 prefix sums under every stream compaction, across the block-count boundaries of its two launches (2048
+    elements per block) — aligned and unaligned inputs.  (A one-launch form for short arrays — a single 1024-thread block —
+    was measured at 12 us per 40 000 elements against 11 us for the two launches: not kept.)"""
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 4097, (n + 3,), generator=g, dtype=torch.int32)
+    for off in (0, 1):
+        xs = x[off: off + n].to(device)
+        if off:
+            xs = x.to(device)[off: off + n]  # a view that starts 4 bytes into the allocation: not 16-byte aligned
+        got = raster.exclusive_scan_i32(xs).cpu()
+        want = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x[off: off + n].long(), 0)]).to(torch.int32)
+        assert torch.equal(got, want), (n, off)

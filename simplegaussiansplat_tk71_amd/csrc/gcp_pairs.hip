@@ -116,14 +116,12 @@ __device__ __forceinline__ int2 rect_at(const void* __restrict__ rects, i64 i) {
   return ok ? make_int2((int)q.x, (int)q.y) : make_int2(-1, -1);
 }
 
-template <bool I64>
-__global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, const SlotLayout L,
-                                                         int2* __restrict__ slots /*tile t: [L.base(t), + L.cap(t)): {index, x | y << 14}*/,
-                                                         int2* __restrict__ pool, unsigned long long* __restrict__ pool_fill,
-                                                         int* __restrict__ pool_off /*[tiles]*/, int* __restrict__ cnt,
-                                                         int* __restrict__ info /*[5]: rows, max x, max y, min, not-boxes flags*/) {
-  __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
-  __shared__ long long s_pool;
+// FULL (compile-time: two straight-line bodies, chosen per block): the tile lies wholly inside the list — every tile but the last
+template <bool I64, bool FULL>
+__device__ __forceinline__ void rect_rows_local_tile(const void* __restrict__ rects, i64 n, const SlotLayout& L, int2* __restrict__ slots,
+                                                     int2* __restrict__ pool, unsigned long long* __restrict__ pool_fill,
+                                                     int* __restrict__ pool_off, int* __restrict__ cnt, int* __restrict__ info,
+                                                     int* s_w, int* s_mx, int* s_my, int* s_mn, long long& s_pool) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 tile = blockIdx.x;
   const i64 base = tile * kElemTile + (i64)w * (256 * kRowsPerThread);
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
   int mx = 0, my = 0, mn = 0x7fffffff;
   const bool vec = (((uintptr_t)rects) & 15u) == 0;
   int2 before[kRowsPerThread];  // the element in front of each row of the wave (what its lane 0 compares with), fetched with the row loads
-  const bool full = (tile + 1) * kElemTile <= n;  // block-uniform: every tile but the last
+  constexpr bool full = FULL;
   if (full) {
     // straight-line: all loads of the lane — its sixteen elements and, at a wave-uniform address (one broadcast line), the
     // element in front of each of its rows — are issued before anything waits.  (Behind a bounds test per element, or with
@@ -206,7 +204,23 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
     __syncthreads();
     if (s_pool >= 0) { fits = true; extra = pool + s_pool; }
   }
-  if (fits) {
+  if (count <= cap) {
+    // the usual case, block-uniform: everything goes to the tile's own slots — a wave-uniform base and a 32-bit slot number,
+    // nothing to choose per record (the kernel spends two thirds of its time issuing vector ALU instructions: 16 elements
+    // per thread, each with its compare chain, its share of the coordinate range and this masked store)
+#pragma unroll
+    for (int r = 0; r < kRowsPerThread; ++r) {
+      const int p32 = (int)(base + r * 256) + lane * 4;  // (n < 2^31)
+      unsigned o = (unsigned)rank[r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((m[r] >> k) & 1u) {
+          mine[o] = make_int2(p32 + k, e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+          ++o;
+        }
+      }
+    }
+  } else if (fits) {
 #pragma unroll
     for (int r = 0; r < kRowsPerThread; ++r) {
       const i64 p = base + r * 256 + lane * 4;
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if ((m[r] >> k) & 1u) {
-          const int2 rec = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));  // x < 10000 < 2^14, y < 2^17 (key < 2^31)
+          const int2 rec = make_int2((int)(p + k), e[r][k].x | (e[r][k].y << 14));
           if (o < cap) mine[o] = rec;
           else extra[o - cap] = rec;
           ++o;
@@ -244,6 +258,20 @@ __global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict_
     if (by > __hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(info + 2, by);
     if (bn < __hip_atomic_load(info + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(info + 3, bn);
   }
+}
+
+template <bool I64>
+__global__ __launch_bounds__(256) void k_rect_rows_local(const void* __restrict__ rects, i64 n, const SlotLayout L,
+                                                         int2* __restrict__ slots /*tile t: [L.base(t), + L.cap(t)): {index, x | y << 14}*/,
+                                                         int2* __restrict__ pool, unsigned long long* __restrict__ pool_fill,
+                                                         int* __restrict__ pool_off /*[tiles]*/, int* __restrict__ cnt,
+                                                         int* __restrict__ info /*[5]: rows, max x, max y, min, not-boxes flags*/) {
+  __shared__ int s_w[4], s_mx[4], s_my[4], s_mn[4];
+  __shared__ long long s_pool;
+  if (((i64)blockIdx.x + 1) * kElemTile <= n)
+    rect_rows_local_tile<I64, true>(rects, n, L, slots, pool, pool_fill, pool_off, cnt, info, s_w, s_mx, s_my, s_mn, s_pool);
+  else
+    rect_rows_local_tile<I64, false>(rects, n, L, slots, pool, pool_fill, pool_off, cnt, info, s_w, s_mx, s_my, s_mn, s_pool);
 }
 
 // The rows of the first cut as the later stages read them: split — the public form, row_start int[rows + 1] (+ sentinel n)

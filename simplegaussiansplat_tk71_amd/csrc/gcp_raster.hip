@@ -70,7 +70,10 @@ constexpr int kTileSX = GCP_TILE_SX, kTileSY = GCP_TILE_SY;
 constexpr int kTileW = 1 << kTileSX, kTileH = 1 << kTileSY;
 constexpr int kWalkThreads = kTileW * kTileH;           // one lane per pixel of the walk's tile
 constexpr bool kWalkSuper = kWalkThreads == 512;
-static_assert(kWalkThreads == 256 || (kTileSX == 5 && kTileSY == 4), "walk tiles: 256 pixels, or 32 x 16 super-tiles");
+#ifndef GCP_WALK_DENSE
+#define GCP_WALK_DENSE 0  // measurement builds: the dense walk below (one wave per tile of any shape up to 1024 pixels)
+#endif
+static_assert(GCP_WALK_DENSE || kWalkThreads == 256 || (kTileSX == 5 && kTileSY == 4), "walk tiles: 256 pixels, or 32 x 16 super-tiles");
 constexpr int kStage = 256;         // list entries staged per LDS round (forward)
 constexpr int kStageBwd = GCP_STAGE_BWD;       // (backward; LDS also holds the per-pixel-row partial sums)
 constexpr int kCkpt = kStageBwd;               // the forward saves every pixel's transmittance every kCkpt list entries
@@ -1200,6 +1203,139 @@ __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendAr
   }
 }
 
+#if GCP_WALK_DENSE
+// ---- measurement build: the DENSE walk on tiles of kTileW x kTileH pixels (<= 1024) --------------------------------------
+// One wave per tile; its lanes are laid over the PAIRS of an entry's box inside the tile, row-major, so that a box that is not
+// cut by the tile's left / right edge is read and written as ONE contiguous run across its rows (consecutive box rows are
+// adjacent in memory): with 64-pixel-wide tiles four boxes in five.  The pixels' running values live in LDS.
+struct DenseBatch {
+  bool in[kWalkBatch];
+  unsigned off[kWalkBatch];
+  int slot[kWalkBatch];
+  float v[kWalkBatch];
+};
+struct DenseCursor {
+  unsigned long long hits;
+  int k, it, nit;
+  __device__ __forceinline__ bool more() const { return hits != 0ull || (k >= 0 && it + 1 < nit); }
+};
+template <int MODE, bool WIDE>
+__device__ __forceinline__ void dense_load(DenseBatch& b, DenseCursor& c, const int4& rec, int lane, const float* __restrict__ x) {
+  constexpr int kUnit = WIDE ? 1 : 4;
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {
+    if (c.k >= 0 && c.it + 1 < c.nit) {
+      ++c.it;
+    } else {
+      if (MODE == 2) {
+        c.k = c.hits ? 63 - __builtin_clzll(c.hits) : -1;
+        c.hits &= ~(1ull << (c.k & 63));
+      } else {
+        c.k = c.hits ? __builtin_ctzll(c.hits) : -1;
+        c.hits &= c.hits - 1ull;
+      }
+      c.it = 0;
+      c.nit = c.k < 0 ? 0 : ((__builtin_amdgcn_readlane(rec.z, c.k & 63) >> 20) & 31);
+    }
+    const int ep = __builtin_amdgcn_readlane(rec.x, c.k & 63), ewd = __builtin_amdgcn_readlane(rec.y, c.k & 63);
+    const int geo = c.k < 0 ? 0 : __builtin_amdgcn_readlane(rec.z, c.k & 63);  // cw | pairs << 8 | parts << 20
+    const int iw = __builtin_amdgcn_readlane(rec.w, c.k & 63);                  // 65536 / cw rounded up | first pixel slot << 17
+    const int cw = geo & 255, tot = (geo >> 8) & 4095, inv = iw & 0x1ffff, sbase = (int)((unsigned)iw >> 17);
+    const int i = lane + 64 * c.it;
+    const int row = (int)(__umul24((unsigned)i, (unsigned)inv) >> 16);  // i / cw, exact for i < 1100 and cw <= 64
+    const int col = i - row * cw;
+    b.in[u] = i < tot;
+    const unsigned o = (unsigned)ep + (unsigned)row * (unsigned)ewd + (unsigned)(col * kUnit);
+    b.off[u] = b.in[u] ? o : 0u;
+    b.slot[u] = sbase + row * kTileW + col;
+    b.v[u] = WIDE ? x[b.off[u]] : *(const float*)((const char*)x + b.off[u]);
+  }
+}
+template <int MODE, bool WIDE, int OUT>
+__device__ __forceinline__ void dense_fold(const DenseBatch& b, float* __restrict__ out, float* __restrict__ acc_lds,
+                                           int* __restrict__ dropped, unsigned char* __restrict__ keep) {
+#pragma unroll
+  for (int u = 0; u < kWalkBatch; ++u) {
+    bool drop = false;
+    if (b.in[u]) {
+      float acc = acc_lds[b.slot[u]];
+      acc = (MODE == 0) ? acc * b.v[u] : acc + b.v[u];
+      acc_lds[b.slot[u]] = acc;
+      drop = acc == 0.0f;
+      const float res = (OUT != kWalkFinal) ? acc : (MODE == 0 ? acc / b.v[u] : acc - b.v[u]);
+      if (WIDE) out[b.off[u]] = res;
+      else *(float*)((char*)out + b.off[u]) = res;
+    }
+    if (OUT != kWalkInclusive) {
+      if (OUT == kWalkFinal && __ballot(drop) != 0ull) {
+        if (drop) keep[WIDE ? b.off[u] : (b.off[u] >> 2)] = 0;
+      }
+      walk_count_dropped<WIDE>(drop, b.off[u], dropped);
+    }
+  }
+}
+template <int MODE, bool WIDE, int OUT>
+__global__ __launch_bounds__(256) void k_pairs_walk_dense(const BlendArgs a, const int* __restrict__ box_off, const float* __restrict__ x,
+                                                          float* __restrict__ out, int* __restrict__ dropped,
+                                                          unsigned char* __restrict__ keep, int n_tiles, int n_blocks, int xcd_remap) {
+  constexpr int kPix = kTileW * kTileH;
+  static_assert(kPix <= 1024 && kTileW <= 64, "dense walk: tiles of at most 1024 pixels, 64 wide");
+  __shared__ float s_acc[4][kPix];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int chunk = (int)sort_chunk(blockIdx.x, n_blocks, xcd_remap);
+  if (chunk < 0) return;
+  const int tile = 4 * chunk + w;
+  if (tile >= n_tiles) return;
+  const int first = a.tile_start[tile], n = a.tile_start[tile + 1] - first;
+  if (n <= 0) return;
+  float* const acc = s_acc[w];
+#pragma unroll
+  for (int j = 0; j < kPix / 64; ++j) acc[lane + 64 * j] = (MODE == 0) ? 1.0f : 0.0f;
+  const int tile_x0 = (tile % a.tiles_x) * kTileW, tile_y0 = (tile / a.tiles_x) * kTileH;
+  constexpr int kUnit = WIDE ? 1 : 4;
+  const int nrounds = (n + kWalkStage - 1) / kWalkStage;
+  for (int q0 = 0; q0 < nrounds; ++q0) {
+    const int q = (MODE == 2) ? (nrounds - 1 - q0) : q0;
+    const int base = first + q * kWalkStage;
+    const int cnt = min(kWalkStage, first + n - base);
+    int4 rec = make_int4(0, 0, 0, 0);
+    bool valid = false;
+    if (lane < cnt) {
+      const i64 g = a.tile_list[base + lane];
+      Box b;
+      load_box(a.start, a.end, g, a.W, a.H, b);
+      const int wd = b.x1 - b.x0 + 1;
+      const int c0 = max(b.x0 - tile_x0, 0), c1 = min(b.x1 - tile_x0, kTileW - 1);
+      const int r0 = max(b.y0 - tile_y0, 0), r1 = min(b.y1 - tile_y0, kTileH - 1);
+      const int cw = c1 - c0 + 1, ch = r1 - r0 + 1;
+      valid = cw > 0 && ch > 0;
+      if (valid) {
+        const unsigned p0 = (unsigned)box_off[g] + (unsigned)(tile_y0 + r0 - b.y0) * (unsigned)wd + (unsigned)(tile_x0 + c0 - b.x0);
+        const int tot = cw * ch;
+        rec = make_int4((int)(p0 * (unsigned)kUnit), wd * kUnit, cw | (tot << 8) | (((tot + 63) >> 6) << 20),
+                        (int)((65535u / (unsigned)cw + 1u) | ((unsigned)(r0 * kTileW + c0) << 17)));
+      }
+    }
+    DenseCursor c;
+    c.hits = __ballot(valid);
+    c.k = -1; c.it = 0; c.nit = 0;
+    if (c.hits) {
+      DenseBatch A, B;
+      dense_load<MODE, WIDE>(A, c, rec, lane, x);
+      for (;;) {
+        if (!c.more()) { dense_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep); break; }
+        dense_load<MODE, WIDE>(B, c, rec, lane, x);
+        dense_fold<MODE, WIDE, OUT>(A, out, acc, dropped, keep);
+        if (!c.more()) { dense_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep); break; }
+        dense_load<MODE, WIDE>(A, c, rec, lane, x);
+        dense_fold<MODE, WIDE, OUT>(B, out, acc, dropped, keep);
+      }
+    }
+  }
+}
+#endif  // GCP_WALK_DENSE
+
 // Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
 // _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
 // One thread per pair; the owning Gaussian is found by bisection in the box offsets.
@@ -1886,8 +2022,15 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
   const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(kWalkThreads);
+#if GCP_WALK_DENSE
+  const int n_blocks = (n_tiles + 3) / 4;
+  const dim3 dgrid(sort_grid(n_blocks, xcd_remap));
+#define GCP_WALK(M, W_, O_) \
+  hipLaunchKernelGGL((k_pairs_walk_dense<M, W_, O_>), dgrid, dim3(256), 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, n_blocks, xcd_remap)
+#else
 #define GCP_WALK(M, W_, O_) \
   hipLaunchKernelGGL((k_pairs_scan_boxes<M, W_, O_>), grid, block, 0, stream, a, box_off, x, out, dropped_per_tile, keep, n_tiles, xcd_remap)
+#endif
 #define GCP_WALK_OUT(M, W_)                                  \
   do {                                                       \
     if (out_mode == kWalkFinal) GCP_WALK(M, W_, kWalkFinal); \

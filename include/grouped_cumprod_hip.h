@@ -341,7 +341,8 @@ int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64
 /* The stream compaction that remains after gcp_pairs_finish_boxes, split at the one device->host read that sizes the result
  * (the reference's `output[mask]`, gs_model.py:575-578, synchronises likewise):
  *   gcp_compact_kept_count: count_dev[0] (device int32) = number of set bytes of keep[begin, end) — the rows a
- *     `cutting_number` slice leaves (gs_model.py:557-559) — and, in ws, the rank of every 4096-element tile of the range.
+ *     `cutting_number` slice leaves (gs_model.py:557-559) — and, in ws, the kept count of every 4096-element tile of the range
+ *     (ONE launch when the walk's counts serve; the prefix sums are made by gcp_compact_kept_write, only when needed).
  *     dropped_per_tile (may be NULL; what the walk counted for the WHOLE array of n_total elements) is used instead of
  *     reading the keep bytes when the range starts at a multiple of 4096 and ends at one or at n_total.
  *   gcp_compact_kept_write: values_out[k] = values_in[i] for the k-th kept i of [begin, end), in order; `ws` as the count
@@ -350,7 +351,7 @@ int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64
 size_t gcp_compact_kept_workspace_bytes(int64_t n);
 int gcp_compact_kept_count(const uint8_t* keep, const int32_t* dropped_per_tile, int64_t n_total, int64_t begin, int64_t end,
                            int32_t* count_dev, void* ws, size_t ws_bytes, void* stream);
-int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, const void* ws,
+int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, void* ws,
                            size_t ws_bytes, void* stream);
 
 /* The rect list of the reference cut back into rectangles (gcp_pairs.hip), so that _create_alpha_brend / grad_cumsum can

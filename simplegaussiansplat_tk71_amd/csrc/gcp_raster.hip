@@ -2077,6 +2077,34 @@ int gcp_pairs_finish_boxes(const int32_t* start_xy, const int32_t* end_xy, int64
 
 size_t gcp_compact_kept_workspace_bytes(int64_t n) { return gcp_compact_workspace_bytes(n); }
 
+// One launch, one block: the per-tile kept counts from what the walk dropped (or, from_dropped = false, the counts as
+// k_count_keep left them) and their TOTAL — all the read-back that sizes the result needs; the prefix sums are only made
+// when something has to be moved (gcp_compact_kept_write).
+static __global__ __launch_bounds__(1024) void k_kept_total(const int* __restrict__ dropped, i64 n, i64 nb, int* __restrict__ cnt,
+                                                            int* __restrict__ count_dev, bool from_dropped) {
+  __shared__ int s_w[16];
+  int s = 0;
+  for (i64 t = threadIdx.x; t < nb; t += 1024) {
+    int c;
+    if (from_dropped) {
+      const i64 len = n - t * kCompactTile;
+      c = (int)(len < kCompactTile ? len : kCompactTile) - dropped[t];
+      cnt[t] = c;
+    } else {
+      c = cnt[t];
+    }
+    s += c;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int j = 0; j < 16; ++j) tot += s_w[j];
+    count_dev[0] = tot;
+  }
+}
+
 int gcp_compact_kept_count(const uint8_t* keep, const int32_t* dropped_per_tile, int64_t n_total, int64_t begin, int64_t end,
                            int32_t* count_dev, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -2094,18 +2122,18 @@ int gcp_compact_kept_count(const uint8_t* keep, const int32_t* dropped_per_tile,
   int* off = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
   int* sws = (int*)p;
   // the walk's own counts serve when the range's tiles are the array's tiles and its last tile is not cut short by `end`
-  if (dropped_per_tile && begin % kCompactTile == 0 && (end == n_total || end % kCompactTile == 0))
-    hipLaunchKernelGGL(k_counts_from_dropped, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream,
-                       dropped_per_tile + begin / kCompactTile, n, nb, cnt);
-  else hipLaunchKernelGGL(k_count_keep, dim3((unsigned)nb), dim3(256), 0, stream, keep + begin, n, cnt);
+  (void)off; (void)sws;  // (the prefix sums are gcp_compact_kept_write's)
+  if (dropped_per_tile && begin % kCompactTile == 0 && (end == n_total || end % kCompactTile == 0)) {
+    hipLaunchKernelGGL(k_kept_total, dim3(1), dim3(1024), 0, stream, dropped_per_tile + begin / kCompactTile, n, nb, cnt, count_dev, true);
+  } else {
+    hipLaunchKernelGGL(k_count_keep, dim3((unsigned)nb), dim3(256), 0, stream, keep + begin, n, cnt);
+    hipLaunchKernelGGL(k_kept_total, dim3(1), dim3(1024), 0, stream, (const int*)nullptr, n, nb, cnt, count_dev, false);
+  }
   GCP_HIP(hipGetLastError());
-  const int st = launch_excl_scan(cnt, off, nb, sws, stream);
-  if (st != GCP_OK) return st;
-  GCP_HIP(hipMemcpyAsync(count_dev, off + nb, sizeof(int), hipMemcpyDeviceToDevice, stream));
   return GCP_OK;
 }
 
-int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, const void* ws,
+int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t begin, int64_t end, float* values_out, void* ws,
                            size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (begin < 0 || end < begin || end - begin > 0x7fffffffLL) return GCP_ERR_INVALID_ARGUMENT;
@@ -2114,7 +2142,12 @@ int gcp_compact_kept_write(const float* values_in, const uint8_t* keep, int64_t 
   if (!values_in || !keep || !values_out || !ws) return GCP_ERR_INVALID_ARGUMENT;
   if (ws_bytes < gcp_compact_kept_workspace_bytes(n)) return GCP_ERR_WORKSPACE;
   const i64 nb = (n + kCompactTile - 1) / kCompactTile;
-  const int* off = (const int*)((const char*)ws + align256((size_t)(nb + 1) * sizeof(int)));
+  // ranks of the tiles from the counts gcp_compact_kept_count left in ws
+  char* p = (char*)ws;
+  const int* cnt = (const int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  int* off = (int*)p; p += align256((size_t)(nb + 1) * sizeof(int));
+  const int st = launch_excl_scan(cnt, off, nb, (int*)p, stream);
+  if (st != GCP_OK) return st;
   const bool vec = (((uintptr_t)(values_in + begin)) & 15u) == 0 && (((uintptr_t)(keep + begin)) & 3u) == 0;
   if (vec) hipLaunchKernelGGL((k_compact_kept<true>), dim3((unsigned)nb), dim3(256), 0, stream, values_in + begin, keep + begin, n, off, values_out);
   else hipLaunchKernelGGL((k_compact_kept<false>), dim3((unsigned)nb), dim3(256), 0, stream, values_in + begin, keep + begin, n, off, values_out);

@@ -23,10 +23,12 @@ def _require(cond, msg):
 def _dev_tensor(t, name, dtype, shape_tail=None):
     _require(isinstance(t, torch.Tensor), f"{name}: expected a torch.Tensor")
     _require(t.is_cuda, f"{name}: expected a ROCm device tensor, got {t.device} (no CPU path)")
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     if t.dtype != dtype:
         t = t.to(dtype)
-    t = t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
     if shape_tail is not None:
         _require(tuple(t.shape[1:]) == tuple(shape_tail), f"{name}: shape {tuple(t.shape)}, expected [N,{shape_tail}]")
     return t
@@ -34,6 +36,24 @@ def _dev_tensor(t, name, dtype, shape_tail=None):
 
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on:
+    """`with _on(device):` — torch.cuda.device(device) only where it is not the current one already (the calls of rows a5 / a6
+    run behind a read-back with the GPU waiting for the next launch: the host work between two launches is on the clock)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, device):
+        self.ctx = None if device.index == torch.cuda.current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 @dataclass
@@ -336,7 +356,7 @@ def finish_buffers(values):
     keep = torch.empty(m, dtype=torch.uint8, device=x.device)
     dropped = torch.empty((m + 4095) // 4096, dtype=torch.int32, device=x.device)
     if m:
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().gcp_pairs_finish_prepare(keep.data_ptr(), dropped.data_ptr(), m, _stream(x.device)), "gcp_pairs_finish_prepare")
     return out, keep, dropped
 
@@ -360,7 +380,7 @@ def finish_boxes(bins, startpoint, endpoint, box_off, values, mode, buffers=None
     if m == 0:
         return out, keep, dropped
     _require(bins.n_tile_pairs > 0, "values: the boxes expand to no pair at all")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().gcp_pairs_finish_boxes(start.data_ptr(), end.data_ptr(), bins.n_gauss, bins.width, bins.height,
                                                       bins.tile_start.data_ptr(), bins.tile_list.data_ptr(), off.data_ptr(), x.data_ptr(),
                                                       out.data_ptr(), keep.data_ptr(), m, int(mode), dropped.data_ptr(), 1 if prepared else 0,
@@ -389,7 +409,7 @@ def compact_kept(final, keep, dropped=None, begin=0, end=None):
     if dropped is not None:
         dropped = _dev_tensor(dropped, "dropped", torch.int32)
         _require(dropped.numel() == (m + 4095) // 4096, "dropped: expected one count per 4096 rows")
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = _stream(dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
         ws = torch.empty(lib.gcp_compact_kept_workspace_bytes(n), dtype=torch.uint8, device=dev)
@@ -417,9 +437,27 @@ class RectBoxes:
     n_tile_pairs: int = None       # its total K
 
     def bin(self):
-        """The rectangles binned into 16x16 tiles (`bin_tiles`), without a second counting pass where the cut has done it."""
-        counted = (self.tile_off, self.n_tile_pairs) if self.tile_off is not None else None
-        return bin_tiles(self.start, self.end, self.width, self.height, counted=counted)
+        """The rectangles binned into 16x16 tiles (`bin_tiles`), without a second counting pass where the cut has done it.
+        (This runs right behind the cut's read-back, with the GPU idle until its first launch: the arrays are the cut's own —
+        int32, contiguous, on one device — so the checks of `bin_tiles` are skipped.)"""
+        if self.tile_off is None:
+            return bin_tiles(self.start, self.end, self.width, self.height)
+        lib = _lib.load()
+        n, K, dev = self.start.size(0), int(self.n_tile_pairs), self.start.device
+        if dev.index != torch.cuda.current_device():
+            return bin_tiles(self.start, self.end, self.width, self.height, counted=(self.tile_off, K))
+        ctx, cty = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.check(lib.gcp_tile_grid(self.width, self.height, ctypes.byref(ctx), ctypes.byref(cty)), "gcp_tile_grid")
+        tx, ty = ctx.value, cty.value
+        tile_start = torch.empty(tx * ty + 1, dtype=torch.int32, device=dev)
+        tile_list = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.gcp_bin_workspace_bytes(n, K), dtype=torch.uint8, device=dev)
+        _lib.check(
+            lib.gcp_bin_tiles_fill(self.start.data_ptr(), self.end.data_ptr(), n, self.width, self.height, self.tile_off.data_ptr(), K,
+                                   tile_start.data_ptr(), tile_list.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            "gcp_bin_tiles_fill",
+        )
+        return TileBins(self.width, self.height, n, K, tx, ty, self.tile_off, tile_start, tile_list[:K])
 
 
 CUT_SLOT_ROWS = 512   # row records a 4096-pair tile may park in the one-call cut: boxes of 8 columns and more
@@ -434,7 +472,7 @@ def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size):
     m = r.size(0)
     dev = r.device
     cap = (m - carry_front - carry_back) // CUT_MIN_RECT + carry_front + carry_back + 16
-    with torch.cuda.device(dev):
+    with _on(dev):
         st = _stream(dev)
         start = torch.empty(cap, 2, dtype=torch.int32, device=dev)
         end = torch.empty(cap, 2, dtype=torch.int32, device=dev)

@@ -2,6 +2,8 @@
 `grad_cumsum` (:716-722) on the HIP library — key-from-rects stable sort, indexed scan, stream compaction — against the
 literal CPU restatement oracle/wrappers.py (itself pinned to the reference Function's outputs in tests/test_oracle.py
 and tests/test_golden_gpu.py), at BASELINE config 2 scene size and on the edge cases of every stage."""
+import os
+
 import pytest
 import torch
 
@@ -854,7 +856,7 @@ def test_one_call_cut_with_carry_rows_and_on_lists_it_has_no_room_for(device):
         raster._cut_rects_once(neg, False, 0, 0, 8)
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("GCP_FUZZ_SEEDS", "24")))))  # a soak run: GCP_FUZZ_SEEDS=600
 def test_default_route_on_random_box_lists(device, seed):
     """Seeded fuzz of the whole default route (one-call cut with its slot / pool / carry-tile layout, binning from the cut's
     counts, the final-value walk, the kept count and the compaction that is left) against the literal CPU statement: random

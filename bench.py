@@ -296,6 +296,14 @@ def wrapper_level(dev, workload):
     raster.rects_to_boxes(rects)
     cut_scratch = (torch.cuda.max_memory_allocated(dev) - held) / m
     del rb
+    # row f3: the per-pixel carry every chunk of the reference's loop ends with (gs_model.py:582-586, :724-730)
+    T_all = ck.create_alpha_brend(rects, anti, "cumprod")[0]
+    T_all = T_all if T_all.numel() == m else anti  # (pairs dropped: the reference thins the list with them; values of any order do)
+    t_min = timed(lambda: ck.create_alpha_brend_min(rects, T_all, image_size=(w, h)))
+    t_min_ext = timed(lambda: ck.create_alpha_brend_min(rects, T_all))
+    t_first = timed(lambda: ck.create_grad_alphabrend_min(rects, grad, image_size=(w, h)))
+    n_pixels = int(ck.create_alpha_brend_min(rects, T_all, image_size=(w, h))[0].size(0))
+    del T_all
     b_rects = sum(sum(v.values()) for v in WRAPPER_BYTES.values())
     b_boxes = sum(sum(v.values()) for v in WRAPPER_BOX_BYTES.values())
     b_auto = sum(sum(v.values()) for v in WRAPPER_AUTO_BYTES.values())
@@ -347,6 +355,18 @@ def wrapper_level(dev, workload):
                                 "indexed scan": roof(sum(WRAPPER_BYTES["indexed scan"].values()), t_scan),
                                 "compaction": roof(sum(WRAPPER_BYTES["compaction"].values()), t_comp)},
             "byte_model": WRAPPER_BYTES,
+        },
+        "chunk_carry": {
+            "what": "_create_alpha_brend_min / create_grad_alphabrend_min (gs_model.py:582-586, :724-730; every chunk of the reference's "
+                    "forward / backward): torch.unique(rects, dim=0) + scatter_reduce(amin) as ONE pass of per-pixel integer minima "
+                    "into an image-sized table, read out in (x, y) order (csrc/gcp_pixels.hip)",
+            "create_alpha_brend_min_ms": t_min,
+            "create_alpha_brend_min_without_image_size_ms": t_min_ext,
+            "create_grad_alphabrend_min_ms": t_first,
+            "distinct_pixels": n_pixels,
+            "roofline": roof(12, t_min),
+            "roofline_first_pair": roof(8, t_first),
+            "byte_model": {"rects read once": 8, "value read (not for the first-pair index)": 4},
         },
         "from_boxes": {
             "what": "the same results from the boxes the rects were expanded from: tile binning + one walk of the tile lists + the same compaction",

@@ -396,6 +396,28 @@ int gcp_rects_cut(const void* rects_xy, int32_t rects_are_int64, int64_t n, int6
                   int64_t rect_capacity, int32_t* start_xy, int32_t* end_xy, int32_t* box_off, int32_t* tile_off, int32_t* info8,
                   void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the per-pixel carry of the reference's chunked calls ----------------------------------
+ * `_create_alpha_brend_min(rects, T)` (gs_model.py:582-586; every forward chunk, :609 / :615) =
+ * torch.unique(rects, dim=0) + scatter_reduce(amin) over its inverse, and `create_grad_alphabrend_min(rects, grad)`
+ * (:724-730; every backward chunk, :639 / :643) = the same with the pair's own index as the value.
+ * gcp_pixels_min: for every distinct pixel of the list — in (x, y) ascending order, the row order of
+ * torch.unique(dim=0) — its coordinates (out_xy, [capacity][2] of the element width of rects_xy) and the minimum of
+ * `values` over its pairs (out_val; a NaN among them gives NaN, as amin does); with values = NULL, the index of its
+ * FIRST pair, as the float the reference carries it in (gs_model.py:728: exact below 2^24, rounded to nearest-even
+ * above).  One pass over the list (integer minima into an image-sized table: the result does not depend on the order
+ * the pairs arrive in), then the table is read out; nothing M-sized is written or sorted.
+ *   width, height: every coordinate must lie in [0, width] x [0, height] (the reference's (H+1) x (W+1) image,
+ *   gs_model.py:505); info (device int32[4]) = {distinct pixels, 1 if a coordinate lay outside (those pairs are
+ *   skipped), 0, 0}.  Rows beyond `capacity` are counted but not written ((width + 1) * (height + 1) always suffices).
+ *   ws: gcp_pixels_min_workspace_bytes(width, height) (0: image too large), 256-byte aligned.
+ * gcp_pixels_range: out3 (device int32[3]) = {max x, max y, min coordinate} of a list, for callers that do not hold
+ * the image size. */
+int gcp_pixels_range(const void* rects_xy, int32_t rects_are_int64, int64_t n, int32_t* out3, void* stream);
+size_t gcp_pixels_min_workspace_bytes(int32_t width, int32_t height);
+int gcp_pixels_min(const void* rects_xy, int32_t rects_are_int64, const float* values /* NULL: the pair's index */, int64_t n,
+                   int32_t width, int32_t height, void* out_xy, float* out_val, int64_t capacity, int32_t* info, void* ws,
+                   size_t ws_bytes, void* stream);
+
 size_t gcp_rects_rows_workspace_bytes(int64_t n);
 int64_t gcp_rects_rows_capacity(int64_t n);
 int gcp_rects_rows(const int32_t* rects_xy, int64_t n, int64_t row_capacity, int32_t* row_start, int32_t* row_xy, int32_t* info,

@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
   grad_cumsum         <- gs_model.py:716-722
   unique              <- gs_model.py:538-541
   mask_zero_T         <- gs_model.py:575-578
+  create_alpha_brend_min / cat_alpha_brend / create_grad_alphabrend_min  <- gs_model.py:582-594, :724-730 (below)
 
 Statement-for-statement, on CPU tensors, with the C oracle in place of the compiled
 extension.  One thing is made explicit: the sort is STABLE.  The reference calls
@@ -59,3 +60,24 @@ def grad_cumsum(rects, grad, cutting_number=None):
     output, mask, _, _ = create_alpha_brend(rects, grad.contiguous(), "cumsum", cutting_number)
     output = output.flip(0)
     return [output, mask]
+
+
+# ---- the per-pixel carry of the chunked calls ----------------------------------------------------
+#   create_alpha_brend_min      <- gs_model.py:582-586  (_create_alpha_brend_min)
+#   cat_alpha_brend             <- gs_model.py:589-594  (_cat_alpha_brend)
+#   create_grad_alphabrend_min  <- gs_model.py:724-730
+# pinned to the reference's own outputs by tests/test_oracle.py (tests/golden/carry_golden.npz)
+def create_alpha_brend_min(rects, T):
+    unique_rects, inv = torch.unique(rects, return_inverse=True, dim=0)
+    T_min = torch.zeros_like(unique_rects[:, 0], dtype=torch.float32).scatter_reduce(0, inv, T, reduce="amin", include_self=False)
+    return [unique_rects, T_min]
+
+
+def cat_alpha_brend(values, rects):
+    return [torch.cat((values[0], values[1]), dim=0), torch.cat((rects[0], rects[1]), dim=0)]
+
+
+def create_grad_alphabrend_min(rects, grad):
+    index = torch.arange(rects.size(0), dtype=torch.int32)
+    unique_rects, first = create_alpha_brend_min(rects, index.to(torch.float32))  # the index travels as a float (:728)
+    return [unique_rects, grad[first.to(torch.int32)]]

@@ -12,7 +12,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("gcp_scan.hip", "gcp_raster.hip", "gcp_pairs.hip", "gcp_project.hip", "gcp_loss.hip", "gcp_optim.hip")]
+SRCS = [os.path.join(PKG_DIR, "csrc", f) for f in ("gcp_scan.hip", "gcp_raster.hip", "gcp_pairs.hip", "gcp_pixels.hip", "gcp_project.hip", "gcp_loss.hip", "gcp_optim.hip")]
 HDRS = [os.path.join(PKG_DIR, "csrc", "gcp_device.hpp")]
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(PKG_DIR, "lib")

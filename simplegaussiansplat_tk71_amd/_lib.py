@@ -86,6 +86,9 @@ SIGNATURES = {
     "gcp_compact_kept_write": (ctypes.c_int, [_c_void_p, _c_void_p, _i64, _i64, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rects_cut_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32, _i64]),
     "gcp_rects_cut": (ctypes.c_int, [_c_void_p, _i32, _i64, _i64, _i64, _i32, _i64] + [_c_void_p] * 6 + [_sz, _c_void_p]),
+    "gcp_pixels_range": (ctypes.c_int, [_c_void_p, _i32, _i64, _c_void_p, _c_void_p]),
+    "gcp_pixels_min_workspace_bytes": (_sz, [_i32, _i32]),
+    "gcp_pixels_min": (ctypes.c_int, [_c_void_p, _i32, _c_void_p, _i64, _i32, _i32, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _sz, _c_void_p]),
     "gcp_rects_rows_workspace_bytes": (_sz, [_i64]),
     "gcp_rects_rows_capacity": (_i64, [_i64]),
     "gcp_rects_rows": (ctypes.c_int, [_c_void_p, _i64, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _sz, _c_void_p]),

@@ -44,6 +44,11 @@ __all__ = [
     "create_alpha_blend",
     "PreparedRects",
     "grad_cumsum",
+    "create_alpha_brend_min",
+    "create_grad_alphabrend_min",
+    "cat_alpha_brend",
+    "create_rects",
+    "mask_zero_T",
     "create_alpha_brend_boxes",
     "grad_cumsum_boxes",
     "custom_autograd_grouped_cumprod",
@@ -457,6 +462,69 @@ def grad_cumsum_boxes(startpoint, endpoint, grad, image_width, image_height, *, 
         return _mask_in_order(_scan_boxes_compact(startpoint, endpoint, grad, image_width, image_height, "cumsum_reverse"), mask_order)
 
 
+def _rects_and_extent(rects, image_size):
+    """(the rect tensor, (width, height) or None) of a tensor or a PreparedRects (whose cut has found the extent)"""
+    if isinstance(rects, PreparedRects):
+        if image_size is None and rects.boxes is not None and rects.shape[0]:
+            image_size = (rects.boxes.width, rects.boxes.height)
+        rects = rects.rects
+    return rects, image_size
+
+
+def create_alpha_brend_min(rects, T, *, image_size=None):
+    """The distinct pixels of `rects` and every pixel's smallest `T` — the carry the reference's chunked forward hands
+    from one chunk to the next (a pixel's transmittance behind the chunk: T only falls along its list).
+
+    reference: gs_model.py:582-586 (`_create_alpha_brend_min`; called by every chunk, :609 / :615):
+    `torch.unique(rects, return_inverse=True, dim=0)` — a lexicographic sort of the M rows — and
+    `scatter_reduce(0, inv, T, "amin", include_self=False)`.  Here: ONE pass over the list, every pair taking the minimum
+    with its pixel's cell of an image-sized table, and the table read out in (x, y) order (csrc/gcp_pixels.hip); nothing
+    M-sized is sorted or written.  Returns [unique_rects (dtype of rects, the rows torch.unique returns in its order),
+    T_min f32] bit for bit — a minimum does not depend on the order it is taken in.  Keyword-only extension:
+    image_size=(width, height), what the Function holds (gs_model.py:666), spares the pass that finds the list's extent;
+    a PreparedRects brings it along."""
+    with torch.no_grad():
+        r, image_size = _rects_and_extent(rects, image_size)
+        u, t_min = _raster.pixels_min(r, T, image_size)
+        return [u, t_min]
+
+
+def create_grad_alphabrend_min(rects, grad, *, image_size=None):
+    """The distinct pixels of `rects` and `grad` at every pixel's FIRST pair — the backward's carry between chunks.
+
+    reference: gs_model.py:724-730: `_create_alpha_brend_min(rects, arange(n).float())`, then `grad[min.to(int32)]` — the
+    index travels as a float32, exact below 2^24 pairs and rounded to nearest-even above (the reference then reads a
+    neighbouring row; reproduced as it is, except that an index rounded up past the last row — a device-side assert
+    there — reads the last row).  Same single pass as `create_alpha_brend_min`, the pair's index in place of a value."""
+    with torch.no_grad():
+        r, image_size = _rects_and_extent(rects, image_size)
+        u, first = _raster.pixels_min(r, None, image_size)
+        n = int(r.shape[0])
+        return [u, grad[first.to(torch.int64).clamp_(max=max(n - 1, 0))]]
+
+
+def cat_alpha_brend(values, rects):
+    """reference: gs_model.py:589-594 (`_cat_alpha_brend`): the carry rows put in front of (forward, :611) or behind
+    (backward, :635) a chunk's own.  Two concatenations."""
+    with torch.no_grad():
+        return [torch.cat((values[0], values[1]), dim=0), torch.cat((rects[0], rects[1]), dim=0)]
+
+
+def create_rects(startpoint, endpoint):
+    """reference: gs_model.py:480-482 (`_create_rects` -> uitility.py:336-366): every pixel of every box, box after box,
+    row-major inside a box, int32 [M,2] (x, y).  One expansion kernel (raster.expand_rects) instead of five M-sized
+    temporaries."""
+    with torch.no_grad():
+        return _raster.expand_rects(startpoint, endpoint, 1 << 30, 1 << 30)
+
+
+def mask_zero_T(T):
+    """reference: gs_model.py:575-578."""
+    with torch.no_grad():
+        mask = T != 0
+        return [T[mask], mask]
+
+
 class custom_autograd_grouped_cumprod(torch.autograd.Function):
     """The reference's rasterise-and-blend Function, same name and call signature
     (reference: gs_model.py:477-820; call site gs_model.py:449):
@@ -476,6 +544,22 @@ class custom_autograd_grouped_cumprod(torch.autograd.Function):
       * dL/dl_d is the true gradient (the reference's is channel-collapsed, SURVEY §0 Q2);
       * deterministic (no atomics); the reference accumulates with index_put_(accumulate=True).
     """
+
+    # The reference's helpers around the scans, under their own names (gs_model.py:480-594, :716-730): code written against
+    # `custom_autograd_grouped_cumprod._create_alpha_brend(...)` etc. — its `_forward_batch` / `_backward_batch` — runs on
+    # the HIP library as it stands.
+    unique = staticmethod(unique)
+    _create_rects = staticmethod(create_rects)
+    _create_alpha_brend = staticmethod(create_alpha_brend)
+    _mask_zero_T = staticmethod(mask_zero_T)
+    _create_alpha_brend_min = staticmethod(create_alpha_brend_min)
+    _cat_alpha_brend = staticmethod(cat_alpha_brend)
+    create_grad_alphabrend_min = staticmethod(create_grad_alphabrend_min)
+
+    @staticmethod
+    def grad_cumsum(rects, grad, cutting_number=None):
+        """gs_model.py:716-722, with the mask in the reference's (flipped) order: `_backward_batch` applies it as it is."""
+        return grad_cumsum(rects, grad, cutting_number, mask_order="reference")
 
     @staticmethod
     def forward(ctx, boxsize, batch, startpoint, endpoint, mean, variance_inverse, opacity, l_d, image_width,

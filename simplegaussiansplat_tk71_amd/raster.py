@@ -552,6 +552,51 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0, carry_at_end=False, one
     return RectBoxes(start, end, box_off, int(max_x), int(max_y))
 
 
+def pixels_min(rects, values=None, image_size=None):
+    """The distinct pixels of a rect list and the minimum of `values` over each one's pairs (csrc/gcp_pixels.hip): what
+    the reference's `_create_alpha_brend_min` (gs_model.py:582-586) gets from `torch.unique(rects, dim=0)` +
+    `scatter_reduce(amin)`.  Returns (unique_rects [U,2] in the dtype of `rects`, rows in (x, y) ascending order — the
+    order torch.unique(dim=0) returns — and out f32[U]).  values=None: `out` is the index of every pixel's FIRST pair as
+    the float `create_grad_alphabrend_min` carries it in (gs_model.py:728).  image_size=(width, height) with every
+    x <= width, y <= height spares the pass that finds the list's extent (one more device->host read); the read that
+    sizes the result (the number of distinct pixels, as torch.unique has it) remains."""
+    i64 = isinstance(rects, torch.Tensor) and rects.dtype == torch.int64
+    r = _dev_tensor(rects, "rects", torch.int64 if i64 else torch.int32, (2,))
+    n = r.size(0)
+    dev = r.device
+    v = None
+    if values is not None:
+        v = _dev_tensor(values, "values", torch.float32)
+        _require(v.dim() == 1 and v.numel() == n, f"values: shape {tuple(v.shape)}, rects has {n} rows")
+        _require(v.device == dev, "values: not on the device of rects")
+    if n == 0:
+        return r.new_empty(0, 2), torch.empty(0, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with _on(dev):
+        st = _stream(dev)
+        if image_size is None:
+            ext = torch.empty(3, dtype=torch.int32, device=dev)
+            _lib.check(lib.gcp_pixels_range(r.data_ptr(), 1 if i64 else 0, n, ext.data_ptr(), st), "gcp_pixels_range")
+            w, h, mn = ext.tolist()
+            _require(mn >= 0, "rects: coordinates must lie in [0, 2^31) (negative ones are not supported)")
+        else:
+            w, h = int(image_size[0]), int(image_size[1])
+            _require(w >= 0 and h >= 0, "image_size: expected width >= 0 and height >= 0")
+        ws_bytes = lib.gcp_pixels_min_workspace_bytes(w, h)
+        _require(ws_bytes > 0, f"rects: a {w + 1} x {h + 1} pixel table is beyond what pixels_min holds")
+        cap = min((w + 1) * (h + 1), n)
+        out_xy = torch.empty(cap, 2, dtype=r.dtype, device=dev)
+        out_val = torch.empty(cap, dtype=torch.float32, device=dev)
+        info = torch.empty(4, dtype=torch.int32, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_pixels_min(r.data_ptr(), 1 if i64 else 0, v.data_ptr() if v is not None else None, n, w, h, out_xy.data_ptr(),
+                                      out_val.data_ptr(), cap, info.data_ptr(), ws.data_ptr(), ws.numel(), st), "gcp_pixels_min")
+        u, outside, _, _ = info.tolist()
+        del ws
+    _require(not outside, f"rects: a coordinate lies outside [0, {w}] x [0, {h}]")
+    return out_xy[:u], out_val[:u]
+
+
 def stable_sort_keys(keys, key_bits=None):
     """Stable sort of non-negative int32 keys on the HIP library: returns (sorted_keys int32[n], index int32[n]) with
     sorted_keys == keys[index] and equal keys in input order — `torch.sort(keys, stable=True)` as the reference needs

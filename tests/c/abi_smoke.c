@@ -188,6 +188,57 @@ static int run_default_route(void) {
   return 0;
 }
 
+/* The per-pixel carry of a chunk (gs_model.py:582-586, :724-730) through the C ABI: the two boxes of run_default_route with
+ * values 0.5 (A) and 0.25 (B): 80 + 80 - 25 distinct pixels in (x, y) order, the minimum 0.25 wherever B lies; with values =
+ * NULL the index of every pixel's first pair. */
+static int run_pixels_min(void) {
+  enum { N = 160, W = 14, H = 10, CELLS = (W + 1) * (H + 1) };
+  int32_t rects[2 * N]; float a[N]; int first[W + 1][H + 1]; float mn[W + 1][H + 1];
+  for (int x = 0; x <= W; ++x) for (int y = 0; y <= H; ++y) { first[x][y] = -1; mn[x][y] = 2.0f; }
+  int64_t p = 0;
+  for (int y = 0; y <= 7; ++y) for (int x = 0; x <= 9; ++x, ++p) { rects[2 * p] = x; rects[2 * p + 1] = y; a[p] = 0.5f; }
+  for (int y = 3; y <= 10; ++y) for (int x = 5; x <= 14; ++x, ++p) { rects[2 * p] = x; rects[2 * p + 1] = y; a[p] = 0.25f; }
+  for (int i = 0; i < N; ++i) {
+    const int x = rects[2 * i], y = rects[2 * i + 1];
+    if (first[x][y] < 0) first[x][y] = i;
+    if (a[i] < mn[x][y]) mn[x][y] = a[i];
+  }
+  int32_t *d_r, *d_xy, *d_info; float *d_a, *d_val; void* ws;
+  const size_t b = gcp_pixels_min_workspace_bytes(W, H);
+  if (!b || hipMalloc((void**)&d_r, sizeof rects) || hipMalloc((void**)&d_a, sizeof a) || hipMalloc((void**)&d_xy, CELLS * 8) ||
+      hipMalloc((void**)&d_val, CELLS * 4) || hipMalloc((void**)&d_info, 16) || hipMalloc(&ws, b)) return 1;
+  hipMemcpy(d_r, rects, sizeof rects, 1); hipMemcpy(d_a, a, sizeof a, 1);
+  for (int index = 0; index < 2; ++index) {
+    CHECK(gcp_pixels_min(d_r, 0, index ? NULL : d_a, N, W, H, d_xy, d_val, CELLS, d_info, ws, b, NULL));
+    hipDeviceSynchronize();
+    int32_t info[4]; hipMemcpy(info, d_info, 16, 2);
+    if (info[0] != 135 || info[1] != 0) { printf("pixels min: info %d %d\n", info[0], info[1]); return 1; }
+    int32_t xy[2 * CELLS]; float val[CELLS];
+    hipMemcpy(xy, d_xy, (size_t)info[0] * 8, 2); hipMemcpy(val, d_val, (size_t)info[0] * 4, 2);
+    int k = 0;
+    for (int x = 0; x <= W; ++x) for (int y = 0; y <= H; ++y) {
+      if (first[x][y] < 0) continue;
+      const float want = index ? (float)first[x][y] : mn[x][y];
+      if (xy[2 * k] != x || xy[2 * k + 1] != y || val[k] != want) { printf("pixels min (%d): row %d is (%d, %d) %g, expected (%d, %d) %g\n", index, k, xy[2 * k], xy[2 * k + 1], val[k], x, y, want); return 1; }
+      ++k;
+    }
+    if (k != info[0]) { printf("pixels min: %d rows checked, %d returned\n", k, info[0]); return 1; }
+  }
+  /* a coordinate outside the image the caller names: flagged, the pair skipped */
+  CHECK(gcp_pixels_min(d_r, 0, d_a, N, W - 1, H, d_xy, d_val, CELLS, d_info, ws, b, NULL));
+  hipDeviceSynchronize();
+  int32_t info[4]; hipMemcpy(info, d_info, 16, 2);
+  if (info[1] != 1) { printf("pixels min: a coordinate outside the image was not flagged\n"); return 1; }
+  int32_t ext[3]; int32_t* d_ext;
+  if (hipMalloc((void**)&d_ext, 12)) return 1;
+  CHECK(gcp_pixels_range(d_r, 0, N, d_ext, NULL));
+  hipDeviceSynchronize();
+  hipMemcpy(ext, d_ext, 12, 2);
+  if (ext[0] != W || ext[1] != H || ext[2] != 0) { printf("pixels range: %d %d %d\n", ext[0], ext[1], ext[2]); return 1; }
+  hipFree(d_r); hipFree(d_a); hipFree(d_xy); hipFree(d_val); hipFree(d_info); hipFree(ws); hipFree(d_ext);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (gcp_abi_version() != GCP_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
   if (argc > 1 && strcmp(argv[1], "link-only") == 0) { printf("link ok, tile = %d elements\n", gcp_tile_elems()); return 0; }
@@ -196,6 +247,7 @@ int main(int argc, char** argv) {
   if (run_alpha_brend()) return 1;
   if (run_rect_cut()) return 1;
   if (run_default_route()) return 1;
+  if (run_pixels_min()) return 1;
   printf("abi_smoke ok\n");
   return 0;
 }

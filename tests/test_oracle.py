@@ -270,3 +270,106 @@ def test_wrappers_oracle_equals_the_reference_with_cumsum_and_cutting_number():
             assert np.array_equal(s.numpy(), z[f"{name}/grad_cumsum_{tag}/values"]), (name, tag)
             n_checked += 1
     assert n_checked >= 8
+
+
+def _carry_golden():
+    import os
+
+    import numpy as np
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "carry_golden.npz"))
+
+
+def test_carry_oracle_equals_the_reference_helpers():
+    """oracle/wrappers.py's `create_alpha_brend_min` / `create_grad_alphabrend_min` against the reference's own
+    (gs_model.py:582-586, :724-730) run on CPU (tests/golden/carry_golden.npz, generator make_carry_golden.py): lists of
+    boxes, a list thinned by a mask, int64 lists, values of both signs and both zeros.  Bit for bit."""
+    import numpy as np
+
+    from oracle import wrappers as ow
+
+    z = _carry_golden()
+    for name in ("m_tiny", "m_small", "m_mid"):
+        rects = torch.from_numpy(z[name + "/rects"])
+        for tag in ("T", "signed"):
+            u, m = ow.create_alpha_brend_min(rects, torch.from_numpy(z[f"{name}/{tag}"]))
+            assert np.array_equal(u.numpy(), z[f"{name}/min_{tag}/unique_rects"]), (name, tag)
+            assert np.array_equal(m.numpy().view(np.int32), z[f"{name}/min_{tag}/values"].view(np.int32)), (name, tag)
+        u, gm = ow.create_grad_alphabrend_min(rects, torch.from_numpy(z[name + "/grad"]))
+        assert np.array_equal(u.numpy(), z[name + "/grad_min/unique_rects"]) and np.array_equal(gm.numpy(), z[name + "/grad_min/values"])
+        keep = torch.from_numpy(z[name + "/masked/keep"])
+        u, m = ow.create_alpha_brend_min(rects[keep], torch.from_numpy(z[name + "/T"])[keep])
+        assert np.array_equal(u.numpy(), z[name + "/masked/unique_rects"]) and np.array_equal(m.numpy(), z[name + "/masked/values"])
+        u, _ = ow.create_alpha_brend_min(rects.long(), torch.from_numpy(z[name + "/T"]))
+        assert u.dtype == torch.int64 and np.array_equal(u.numpy(), z[name + "/min_T_i64/unique_rects"])
+
+
+def carry_chain(z, name, F, rects_of, to_dev=lambda t: t):
+    """The reference's chunk loop (gs_model.py:601-615 forward, :634-643 backward, last chunk first) on the functions of
+    `F` (the oracle's, or the HIP module's under the reference's names), compared step by step with what the reference
+    itself returned (carry_golden.npz).  rects_of(start, end) expands a chunk's boxes; exact=False: values within the
+    tolerance rule (the HIP scans associate differently), masks / pixels / carried rows bit for bit."""
+    import numpy as np
+
+    ends = z[name + "/chunk_ends"].tolist()
+    start, end = torch.from_numpy(z[name + "/start"]), torch.from_numpy(z[name + "/end"])
+    got = {}
+    unique_rects, T_min, kept = None, None, []
+    for c in range(len(ends)):
+        s0 = ends[c - 1] if c else 0
+        rects = rects_of(to_dev(start[s0:ends[c]]), to_dev(end[s0:ends[c]]))
+        anti = to_dev(torch.from_numpy(z[f"{name}/fwd{c}/anti_opacity"]))
+        if unique_rects is None:
+            T, mask = F._create_alpha_brend(rects, anti, flag="cumprod")[:2]
+            rects = rects[mask]
+            unique_rects, T_min = F._create_alpha_brend_min(rects, T)
+        else:
+            cat_anti, cat_rects = F._cat_alpha_brend([T_min, anti], [unique_rects, rects])
+            T, mask = F._create_alpha_brend(cat_rects, cat_anti, flag="cumprod", cutting_number=len(unique_rects))[:2]
+            rects = rects[mask]
+            cat_anti, cat_rects = F._cat_alpha_brend([T_min, T], [unique_rects, rects])
+            unique_rects, T_min = F._create_alpha_brend_min(cat_rects, cat_anti)
+        kept.append(rects)
+        got[f"fwd{c}/T"], got[f"fwd{c}/mask"], got[f"fwd{c}/unique_rects"], got[f"fwd{c}/T_min"] = T, mask, unique_rects, T_min
+    unique_rects, grad_cumsum_0 = None, None
+    for c in reversed(range(len(ends))):
+        rects = kept[c]
+        pixel_grad = to_dev(torch.from_numpy(z[f"{name}/bwd{c}/pixel_grad"]))
+        if unique_rects is not None:
+            cat_grad, cat_rects = F._cat_alpha_brend([pixel_grad, grad_cumsum_0], [rects, unique_rects])
+            pixel_grad_cumsum, mask = F.grad_cumsum(cat_rects, cat_grad, len(unique_rects))
+            rects = rects[mask]
+            cat_grad, cat_rects = F._cat_alpha_brend([pixel_grad_cumsum, grad_cumsum_0], [rects, unique_rects])
+            unique_rects, grad_cumsum_0 = F.create_grad_alphabrend_min(cat_rects, cat_grad)
+        else:
+            pixel_grad_cumsum, mask = F.grad_cumsum(rects, pixel_grad)
+            rects = rects[mask]
+            unique_rects, grad_cumsum_0 = F.create_grad_alphabrend_min(rects, pixel_grad_cumsum)
+        got[f"bwd{c}/pixel_grad_cumsum"], got[f"bwd{c}/mask"] = pixel_grad_cumsum, mask
+        got[f"bwd{c}/unique_rects"], got[f"bwd{c}/grad_cumsum_0"] = unique_rects, grad_cumsum_0
+    return {k: v.cpu().numpy() for k, v in got.items()}
+
+
+def test_carry_oracle_runs_the_reference_chunk_loop_to_the_reference_results():
+    import types
+
+    import numpy as np
+
+    from oracle import wrappers as ow
+
+    F = types.SimpleNamespace(_create_alpha_brend=ow.create_alpha_brend, _create_alpha_brend_min=ow.create_alpha_brend_min,
+                              _cat_alpha_brend=ow.cat_alpha_brend, grad_cumsum=ow.grad_cumsum,
+                              create_grad_alphabrend_min=ow.create_grad_alphabrend_min)
+    z = _carry_golden()
+
+    def rects_of(start, end):  # uitility.py:336-366, box after box
+        rows = []
+        for (x0, y0), (x1, y1) in zip(start.tolist(), end.tolist()):
+            ys, xs = torch.meshgrid(torch.arange(y0, y1 + 1), torch.arange(x0, x1 + 1), indexing="ij")
+            rows.append(torch.stack((xs.flatten(), ys.flatten()), 1))
+        return torch.cat(rows).to(torch.int32)
+
+    for name in ("chain_small", "chain_mid"):
+        got = carry_chain(z, name, F, rects_of)
+        for k, v in got.items():
+            assert np.array_equal(v, z[f"{name}/{k}"]), (name, k)

@@ -3,7 +3,7 @@ sizes: whole-call times of create_alpha_brend(rects), create_alpha_brend_boxes, 
 stage of the rects route timed on its own.  Run it under `rocprofv3 --kernel-trace --stats` for the kernel table that
 profiles/r03_wrappers.md quotes.
 
-  python tools/wrapper_bench.py [cfg2 cfg3] [--stages] [--chunked] [--iters 5]
+  python tools/wrapper_bench.py [cfg2 cfg3] [--stages] [--chunked] [--carry | --only-carry] [--iters 5]
 """
 import json
 import os
@@ -69,16 +69,21 @@ def main():
         out = {"workload": cfg, "pairs": m, "gaussians": int(sc["start"].size(0))}
         bits = ck.pixel_key_bits(w, h)
         out["key_bits"] = bits
+        only_carry = "--only-carry" in argv  # (A/B runs of csrc/gcp_pixels.hip: tools/pixels_ab.sh)
         out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), iters)  # auto: cut into boxes, walk
-        out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad), iters)
-        out["rects_to_boxes_ms"] = timeit(lambda: raster.rects_to_boxes(rects), iters)
-        out["sort_route_create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort"), iters)
-        out["sort_route_create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", image_size=(w, h), route="sort"), iters)
-        out["sort_route_grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort"), iters)
-        out["sort_route_key_bits_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits, route="sort"), iters)
-        out["sort_route_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", route="sort"), iters)
-        out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
-        out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
+        if only_carry:
+            argv = [a for a in argv if a not in ("--stages", "--chunked")] + ["--carry"]
+            stages = False
+        else:
+            out["grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad), iters)
+            out["rects_to_boxes_ms"] = timeit(lambda: raster.rects_to_boxes(rects), iters)
+            out["sort_route_create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(w, h), route="sort"), iters)
+            out["sort_route_create_alpha_brend_cumsum_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumsum", image_size=(w, h), route="sort"), iters)
+            out["sort_route_grad_cumsum_ms"] = timeit(lambda: ck.grad_cumsum(rects, grad, image_size=(w, h), route="sort"), iters)
+            out["sort_route_key_bits_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", key_bits=bits, route="sort"), iters)
+            out["sort_route_key_range_read_back_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", route="sort"), iters)
+            out["create_alpha_brend_boxes_ms"] = timeit(lambda: ck.create_alpha_brend_boxes(sc["start"], sc["end"], anti, w, h, "cumprod"), iters)
+            out["grad_cumsum_boxes_ms"] = timeit(lambda: ck.grad_cumsum_boxes(sc["start"], sc["end"], grad, w, h), iters)
         if "--chunked" in argv:
             # a second chunk's call (gs_model.py:611-612): the image's pixels as carry rows in torch.unique's order, then the boxes
             xs = torch.arange(w + 1, device=dev, dtype=torch.int32)
@@ -91,6 +96,35 @@ def main():
             out["chunked_call_create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(lst, vals, "cumprod", c), iters)
             out["chunked_call_sort_route_ms"] = timeit(lambda: ck.create_alpha_brend(lst, vals, "cumprod", c, image_size=(w, h), route="sort"), iters)
             del lst, vals, carry
+        if "--carry" in argv:
+            # row f3: the per-pixel carry of the chunk loop (gs_model.py:582-586, :724-730), and the reference's own statement
+            # of it — torch.unique(dim=0) + scatter_reduce(amin) — run by torch on the same device
+            T, _ = ck.create_alpha_brend(rects, anti, "cumprod")  # what the reference calls it on (gs_model.py:607-609): falls along a pixel's list
+            if T.numel() != m:  # (pairs were dropped: the list would have to be thinned with them)
+                T = anti
+            out["create_alpha_brend_min_ms"] = timeit(lambda: ck.create_alpha_brend_min(rects, T, image_size=(w, h)), iters)
+            out["create_alpha_brend_min_unordered_values_ms"] = timeit(lambda: ck.create_alpha_brend_min(rects, anti, image_size=(w, h)), iters)
+            out["create_alpha_brend_min_extent_read_back_ms"] = timeit(lambda: ck.create_alpha_brend_min(rects, T), iters)
+            out["create_grad_alphabrend_min_ms"] = timeit(lambda: ck.create_grad_alphabrend_min(rects, grad, image_size=(w, h)), iters)
+            out["create_alpha_brend_min_int64_ms"] = None
+            if m <= 200_000_000:
+                r64 = rects.long()
+                out["create_alpha_brend_min_int64_ms"] = timeit(lambda: ck.create_alpha_brend_min(r64, T, image_size=(w, h)), iters)
+                del r64
+            u, _ = ck.create_alpha_brend_min(rects, T, image_size=(w, h))
+            out["distinct_pixels"] = int(u.size(0))
+            del u, T
+
+            def torch_statement():
+                unique_rects, inv = torch.unique(rects, return_inverse=True, dim=0)
+                return torch.zeros_like(unique_rects[:, 0], dtype=torch.float32).scatter_reduce(0, inv, anti, reduce="amin", include_self=False)
+
+            try:
+                out["torch_unique_dim0_scatter_amin_ms"] = timeit(torch_statement, 2, 1)
+            except RuntimeError as e:  # out of memory at the larger scenes: said, not hidden
+                out["torch_unique_dim0_scatter_amin_ms"] = None
+                out["torch_unique_dim0_error"] = str(e).splitlines()[0][:160]
+                torch.cuda.empty_cache()
         if stages:
             import grouped_cumprod as gc
 

@@ -361,7 +361,7 @@ def wrapper_level(dev, workload):
                     "forward / backward): torch.unique(rects, dim=0) + scatter_reduce(amin) as ONE pass of per-pixel integer minima "
                     "into an image-sized table, read out in (x, y) order (csrc/gcp_pixels.hip)",
             "create_alpha_brend_min_ms": t_min,
-            "create_alpha_brend_min_without_image_size_ms": t_min_ext,
+            "create_alpha_brend_min_without_image_size_ms": t_min_ext,  # (the list's extent is measured once per device and remembered)
             "create_grad_alphabrend_min_ms": t_first,
             "distinct_pixels": n_pixels,
             "roofline": roof(12, t_min),

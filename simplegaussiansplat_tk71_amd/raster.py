@@ -552,14 +552,21 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0, carry_at_end=False, one
     return RectBoxes(start, end, box_off, int(max_x), int(max_y))
 
 
+_extent_seen = {}  # device index -> (width, height): the largest list extent pixels_min has measured there
+_EXTENT_CACHE_CELLS = 1 << 24
+
+
 def pixels_min(rects, values=None, image_size=None):
     """The distinct pixels of a rect list and the minimum of `values` over each one's pairs (csrc/gcp_pixels.hip): what
     the reference's `_create_alpha_brend_min` (gs_model.py:582-586) gets from `torch.unique(rects, dim=0)` +
     `scatter_reduce(amin)`.  Returns (unique_rects [U,2] in the dtype of `rects`, rows in (x, y) ascending order — the
     order torch.unique(dim=0) returns — and out f32[U]).  values=None: `out` is the index of every pixel's FIRST pair as
-    the float `create_grad_alphabrend_min` carries it in (gs_model.py:728).  image_size=(width, height) with every
-    x <= width, y <= height spares the pass that finds the list's extent (one more device->host read); the read that
-    sizes the result (the number of distinct pixels, as torch.unique has it) remains."""
+    the float `create_grad_alphabrend_min` carries it in (gs_model.py:728).
+    image_size=(width, height) with every x <= width, y <= height sizes the pixel table.  Without it the list's extent is
+    measured (one more pass over the list and one more device->host read) and remembered per device: the next call there
+    starts from the remembered extent — any table that holds the list gives the same result — and measures again only if a
+    coordinate falls outside it (the kernel says so), so a training loop pays for the measurement once.  The read that sizes
+    the result (the number of distinct pixels, as torch.unique has it) remains in every case."""
     i64 = isinstance(rects, torch.Tensor) and rects.dtype == torch.int64
     r = _dev_tensor(rects, "rects", torch.int64 if i64 else torch.int32, (2,))
     n = r.size(0)
@@ -572,16 +579,8 @@ def pixels_min(rects, values=None, image_size=None):
     if n == 0:
         return r.new_empty(0, 2), torch.empty(0, dtype=torch.float32, device=dev)
     lib = _lib.load()
-    with _on(dev):
-        st = _stream(dev)
-        if image_size is None:
-            ext = torch.empty(3, dtype=torch.int32, device=dev)
-            _lib.check(lib.gcp_pixels_range(r.data_ptr(), 1 if i64 else 0, n, ext.data_ptr(), st), "gcp_pixels_range")
-            w, h, mn = ext.tolist()
-            _require(mn >= 0, "rects: coordinates must lie in [0, 2^31) (negative ones are not supported)")
-        else:
-            w, h = int(image_size[0]), int(image_size[1])
-            _require(w >= 0 and h >= 0, "image_size: expected width >= 0 and height >= 0")
+
+    def run(w, h):
         ws_bytes = lib.gcp_pixels_min_workspace_bytes(w, h)
         _require(ws_bytes > 0, f"rects: a {w + 1} x {h + 1} pixel table is beyond what pixels_min holds")
         cap = min((w + 1) * (h + 1), n)
@@ -590,11 +589,33 @@ def pixels_min(rects, values=None, image_size=None):
         info = torch.empty(4, dtype=torch.int32, device=dev)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.gcp_pixels_min(r.data_ptr(), 1 if i64 else 0, v.data_ptr() if v is not None else None, n, w, h, out_xy.data_ptr(),
-                                      out_val.data_ptr(), cap, info.data_ptr(), ws.data_ptr(), ws.numel(), st), "gcp_pixels_min")
+                                      out_val.data_ptr(), cap, info.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "gcp_pixels_min")
         u, outside, _, _ = info.tolist()
-        del ws
-    _require(not outside, f"rects: a coordinate lies outside [0, {w}] x [0, {h}]")
-    return out_xy[:u], out_val[:u]
+        return None if outside else (out_xy[:u], out_val[:u])
+
+    with _on(dev):
+        if image_size is not None:
+            w, h = int(image_size[0]), int(image_size[1])
+            _require(w >= 0 and h >= 0, "image_size: expected width >= 0 and height >= 0")
+            out = run(w, h)
+            _require(out is not None, f"rects: a coordinate lies outside [0, {w}] x [0, {h}]")
+            return out
+        seen = _extent_seen.get(dev.index)
+        if seen is not None:
+            out = run(*seen)
+            if out is not None:
+                return out
+        ext = torch.empty(3, dtype=torch.int32, device=dev)
+        _lib.check(lib.gcp_pixels_range(r.data_ptr(), 1 if i64 else 0, n, ext.data_ptr(), _stream(dev)), "gcp_pixels_range")
+        w, h, mn = ext.tolist()
+        _require(mn >= 0, "rects: coordinates must lie in [0, 2^31) (negative ones are not supported)")
+        if seen is not None and (max(w, seen[0]) + 1) * (max(h, seen[1]) + 1) <= _EXTENT_CACHE_CELLS:
+            w, h = max(w, seen[0]), max(h, seen[1])
+        if (w + 1) * (h + 1) <= _EXTENT_CACHE_CELLS:
+            _extent_seen[dev.index] = (w, h)
+        out = run(w, h)
+        _require(out is not None, "pixels_min: the measured extent does not hold the list")
+        return out
 
 
 def stable_sort_keys(keys, key_bits=None):

@@ -152,6 +152,39 @@ def test_edges_empty_one_pixel_nan_and_coordinates_outside(device):
         ck.create_alpha_brend_min(r.cpu(), v.cpu())
 
 
+def test_the_remembered_extent_never_changes_a_result(device):
+    """Without image_size the extent of the list is measured once per device and remembered; a later list is first tried
+    against the remembered extent and measured only if a coordinate falls outside it.  Same results either way."""
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+
+    g = torch.Generator().manual_seed(9)
+
+    def check(w, h, n):
+        r = torch.stack((torch.randint(0, w + 1, (n,), generator=g), torch.randint(0, h + 1, (n,), generator=g)), 1).to(torch.int32)
+        t = torch.rand(n, generator=g)
+        wu, wm = ow.create_alpha_brend_min(r, t)
+        u, m = ck.create_alpha_brend_min(r.to(device), t.to(device))
+        assert torch.equal(u.cpu(), wu) and np.array_equal(_bits(m), _bits(wm)), (w, h, n)
+
+    raster._extent_seen.pop(device.index, None)
+    check(40, 30, 5000)            # measured: (<= 40, <= 30) remembered
+    seen = raster._extent_seen[device.index]
+    assert seen[0] <= 40 and seen[1] <= 30
+    check(20, 10, 3000)            # fits the remembered extent: no measurement, a larger table than needed
+    assert raster._extent_seen[device.index] == seen
+    check(90, 12, 4000)            # wider: the kernel reports a coordinate outside, the extent is measured again and grows
+    grown = raster._extent_seen[device.index]
+    assert grown[0] > seen[0] and grown[1] >= seen[1]
+    check(15, 70, 4000)            # taller
+    assert raster._extent_seen[device.index][1] > grown[1]
+    bad = torch.tensor([[3, 4], [-1, 2]], dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError, match="negative"):
+        ck.create_alpha_brend_min(bad, torch.ones(2, device=device))
+    raster._extent_seen.pop(device.index, None)
+
+
 def test_first_pair_index_travels_as_a_float_like_the_reference(device):
     """gs_model.py:728: the index goes through fp32 — exact below 2^24, rounded to nearest-even above, and the reference
     then reads the row it was rounded to.  The expectation is the statement itself, on the first indices constructed."""

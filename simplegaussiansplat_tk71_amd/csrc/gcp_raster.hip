@@ -1338,23 +1338,51 @@ __global__ __launch_bounds__(256) void k_pairs_walk_dense(const BlendArgs a, con
 
 // Gaussian-major rect list (reference: Utilities.make_rect_points_parallel, uitility.py:336-366, called by
 // _create_rects, gs_model.py:480-482): pair i of Gaussian g is pixel (x0 + i % w, y0 + i / w) of its box.
-// One thread per pair; the owning Gaussian is found by bisection in the box offsets.
-__global__ void k_expand_rects(const int* start, const int* end, const int* box_off, i64 n_gauss, i64 m, int W, int H,
-                               int* rects /*[m][2]*/, int* pair_gauss /*[m] or null*/) {
-  const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  i64 lo = 0, hi = n_gauss;  // last g with box_off[g] <= i
-  while (hi - lo > 1) {
-    const i64 mid = (lo + hi) >> 1;
-    if (box_off[mid] <= i) lo = mid; else hi = mid;
-  }
+// Parallel over the BOXES, not over the pairs: a block takes kExpandBoxes consecutive Gaussians, each wave writes one box
+// at a time — its lanes over consecutive pairs, 512 contiguous bytes per store instruction — and a box of more than
+// kExpandBig pairs is written by the whole block.  Nothing is searched (one thread per pair had to find its Gaussian by a
+// 20-step bisection of dependent loads in the box offsets: 2.2 ms for 1.65e8 pairs, 0.6 TB/s of stores), and the box's
+// width is wave-uniform: i / w is one multiplication by its reciprocal and one correction step (exact: i < 2^24).
+constexpr int kExpandBoxes = 64;
+constexpr int kExpandBig = 8192;
+
+template <bool BIG>
+__device__ __forceinline__ void expand_box(const int* __restrict__ start, const int* __restrict__ end, const int* __restrict__ box_off, i64 g,
+                                           i64 m, int W, int H, int t, int step, int2* __restrict__ rects, int* __restrict__ pair_gauss) {
   Box b;
-  load_box(start, end, lo, W, H, b);
-  const int local = (int)(i - box_off[lo]);
-  const int w = b.x1 - b.x0 + 1;
-  rects[2 * i] = b.x0 + local % w;
-  rects[2 * i + 1] = b.y0 + local / w;
-  if (pair_gauss) pair_gauss[i] = (int)lo;
+  if (!load_box(start, end, g, W, H, b)) return;
+  const int bw = b.x1 - b.x0 + 1;
+  i64 size = (i64)bw * (b.y1 - b.y0 + 1);
+  if ((size > kExpandBig) != BIG) return;
+  const i64 off = box_off[g];
+  if (off < 0 || off > m) return;  // (offsets that do not belong to these boxes: nothing is written outside the list)
+  size = min(size, m - off);
+  if (size < (1 << 24)) {
+    const float rw = 1.0f / (float)bw;
+    for (int l = t; l < (int)size; l += step) {
+      int q = (int)((float)l * rw), r = l - q * bw;
+      if (r < 0) { --q; r += bw; }
+      else if (r >= bw) { ++q; r -= bw; }
+      rects[off + l] = make_int2(b.x0 + r, b.y0 + q);
+      if (pair_gauss) pair_gauss[off + l] = (int)g;
+    }
+  } else {
+    for (i64 l = t; l < size; l += step) {
+      const i64 q = l / bw;
+      rects[off + l] = make_int2(b.x0 + (int)(l - q * bw), b.y0 + (int)q);
+      if (pair_gauss) pair_gauss[off + l] = (int)g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_expand_rects(const int* __restrict__ start, const int* __restrict__ end, const int* __restrict__ box_off,
+                                                      i64 n_gauss, i64 m, int W, int H, int2* __restrict__ rects /*[m]*/,
+                                                      int* __restrict__ pair_gauss /*[m] or null*/) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const i64 b0 = (i64)blockIdx.x * kExpandBoxes, b1 = min(n_gauss, b0 + kExpandBoxes);
+  for (i64 g = b0 + w; g < b1; g += 4) expand_box<false>(start, end, box_off, g, m, W, H, lane, 64, rects, pair_gauss);
+  for (i64 g = b0; g < b1; ++g) expand_box<true>(start, end, box_off, g, m, W, H, (int)threadIdx.x, 256, rects, pair_gauss);
 }
 
 // ---- the index plumbing around the scan in _create_alpha_brend (gs_model.py:548, :555-564) --------------
@@ -2174,8 +2202,8 @@ int gcp_expand_rects(const int32_t* start_xy, const int32_t* end_xy, const int32
   if (n_gauss < 0 || n_pairs < 0 || width < 0 || height < 0) return GCP_ERR_INVALID_ARGUMENT;
   if (n_pairs == 0) return GCP_OK;
   if (!start_xy || !end_xy || !box_off || !rects_xy || n_gauss == 0) return GCP_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_expand_rects, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, start_xy, end_xy,
-                     box_off, (i64)n_gauss, (i64)n_pairs, width, height, rects_xy, pair_gauss);
+  hipLaunchKernelGGL(k_expand_rects, dim3((unsigned)((n_gauss + kExpandBoxes - 1) / kExpandBoxes)), dim3(256), 0, stream, start_xy, end_xy,
+                     box_off, (i64)n_gauss, (i64)n_pairs, width, height, (int2*)rects_xy, pair_gauss);
   GCP_HIP(hipGetLastError());
   return GCP_OK;
 }

@@ -295,6 +295,61 @@ def test_expand_rects_matches_reference_order(device):
     assert rects.size(0) == int(sc["boxsize"].sum())
 
 
+def test_expand_rects_every_box_size_class_and_the_reference_names(device):
+    """One-pixel boxes, boxes that miss the image (no pairs), boxes written by one wave and by the whole block (> 8192
+    pairs), more boxes than one block takes, a box of more than 2^24 pairs (the exact-division branch) — against the
+    closed form: pair i of box g is (x0 + i % w, y0 + i // w); and `custom_autograd_grouped_cumprod._create_rects` against the
+    rect lists the reference itself produced (tests/golden/carry_golden.npz)."""
+    import numpy as np
+
+    from simplegaussiansplat_tk71_amd import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import raster
+    from tests.test_oracle import _carry_golden
+
+    def closed_form(s, e, w, h):
+        x0, y0 = s[:, 0].clamp(min=0).long(), s[:, 1].clamp(min=0).long()
+        x1, y1 = e[:, 0].clamp(max=w).long(), e[:, 1].clamp(max=h).long()
+        bw, bh = (x1 - x0 + 1).clamp(min=0), (y1 - y0 + 1).clamp(min=0)
+        size = torch.where((bw > 0) & (bh > 0), bw * bh, torch.zeros_like(bw))
+        owner = torch.repeat_interleave(torch.arange(s.size(0)), size)
+        local = torch.arange(int(size.sum())) - torch.repeat_interleave(torch.cumsum(size, 0) - size, size)
+        return torch.stack((x0[owner] + local % bw[owner], y0[owner] + local // bw[owner]), 1), owner
+
+    g = torch.Generator().manual_seed(5)
+    n = 700
+    s = torch.stack((torch.randint(0, 3000, (n,), generator=g), torch.randint(0, 2000, (n,), generator=g)), 1).to(torch.int32)
+    half = torch.randint(0, 12, (n, 2), generator=g).to(torch.int32)
+    e = s + half
+    e[::7] = s[::7]                      # one-pixel boxes
+    e[3::50, 0] = s[3::50, 0] - 1        # empty
+    s[5], e[5] = torch.tensor([10, 20]), torch.tensor([200, 120])      # 191 x 101 = 19 291 pairs: the whole block
+    s[640], e[640] = torch.tensor([0, 0]), torch.tensor([2999, 1999])  # 6e6 pairs
+    s[77], e[77] = torch.tensor([2990, 1990]), torch.tensor([3100, 2100])  # cut by the image
+    want, wown = closed_form(s, e, 2999, 1999)
+    rects, owner = raster.expand_rects(s.to(device), e.to(device), 2999, 1999, with_gaussian=True)
+    assert torch.equal(rects.cpu().long(), want) and torch.equal(owner.cpu().long(), wown)
+    # more than 2^24 pairs in one box
+    s2 = torch.tensor([[1, 2], [0, 0], [4, 4]], dtype=torch.int32)
+    e2 = torch.tensor([[3, 2], [4999, 3999], [4, 5]], dtype=torch.int32)
+    want, _ = closed_form(s2, e2, 5000, 4000)
+    rects = raster.expand_rects(s2.to(device), e2.to(device), 5000, 4000)
+    assert rects.size(0) == 3 + 20_000_000 + 2 and torch.equal(rects.cpu().long(), want)
+    # the reference's own lists, under its own name
+    z = _carry_golden()
+    for name in ("chain_small", "chain_mid"):
+        start, end = torch.from_numpy(z[name + "/start"]), torch.from_numpy(z[name + "/end"])
+        got = ck.custom_autograd_grouped_cumprod._create_rects(start.to(device), end.to(device))
+        want, _ = closed_form(start, end, 1 << 30, 1 << 30)
+        assert got.dtype == torch.int32 and torch.equal(got.cpu().long(), want)
+    for name in ("m_tiny", "m_small", "m_mid"):  # (rects stored by the reference's _create_rects; the scene it came from is make_scene's)
+        from tests.golden.make_function_golden import make_scene as golden_scene
+
+        n_gauss, w, h, mh, seed = {"m_tiny": (5, 10, 8, 2, 51), "m_small": (40, 33, 17, 4, 52), "m_mid": (260, 64, 48, 5, 53)}[name]
+        sc = golden_scene(n_gauss, w, h, mh, seed)
+        got = ck.create_rects(sc["start"].to(device), sc["end"].to(device))
+        assert np.array_equal(got.cpu().numpy(), z[name + "/rects"])
+
+
 def test_bin_tiles_refuses_more_than_int32_entries(device):
     """80 000 Gaussians that each cover a 3840x2160 frame would need 2.6e9 (tile, Gaussian) entries."""
     from simplegaussiansplat_tk71_amd import raster

@@ -111,6 +111,7 @@ def main():
                 r64 = rects.long()
                 out["create_alpha_brend_min_int64_ms"] = timeit(lambda: ck.create_alpha_brend_min(r64, T, image_size=(w, h)), iters)
                 del r64
+            out["create_rects_ms"] = timeit(lambda: ck.create_rects(sc["start"], sc["end"]), iters)  # _create_rects (gs_model.py:480-482): expansion + the read-back of M
             u, _ = ck.create_alpha_brend_min(rects, T, image_size=(w, h))
             out["distinct_pixels"] = int(u.size(0))
             del u, T

@@ -112,6 +112,16 @@ def main():
                 out["create_alpha_brend_min_int64_ms"] = timeit(lambda: ck.create_alpha_brend_min(r64, T, image_size=(w, h)), iters)
                 del r64
             out["create_rects_ms"] = timeit(lambda: ck.create_rects(sc["start"], sc["end"]), iters)  # _create_rects (gs_model.py:480-482): expansion + the read-back of M
+            F = ck.custom_autograd_grouped_cumprod
+
+            def first_chunk():  # the scan side of `_forward_batch` for a first chunk (gs_model.py:601, :607-609), under the reference's names
+                r = F._create_rects(sc["start"], sc["end"])
+                t, mask = F._create_alpha_brend(r, anti, flag="cumprod")
+                r = r[mask]
+                return F._create_alpha_brend_min(r, t)
+
+            out["first_chunk_scan_side_ms"] = timeit(first_chunk, iters)
+            out["first_chunk_of_which_rects_mask_indexing_ms"] = timeit(lambda: rects[torch.ones(m, dtype=torch.bool, device=dev)], iters)
             u, _ = ck.create_alpha_brend_min(rects, T, image_size=(w, h))
             out["distinct_pixels"] = int(u.size(0))
             del u, T

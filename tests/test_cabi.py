@@ -173,3 +173,39 @@ def test_walk_compaction_and_blend_kernels_use_no_scratch(tmp_path):
     assert not bad, bad
     # eight waves per SIMD need <= 64 VGPRs, six <= 80: nothing on these paths may slip under six
     assert max(int(v) for ks in seen.values() for _, _, v, _ in ks) <= 80
+
+
+def test_chunk_carry_entry_points_validate_without_a_gpu_and_the_reference_names_exist():
+    """Row f3 widened: the argument checks of gcp_pixels_min / gcp_pixels_range return before any HIP call; the workspace covers
+    the pixel table; the reference's helper names (gs_model.py:480-594, :716-730) are static methods of the Function class."""
+    import pytest
+    import torch
+
+    import cuda_kernel as ck
+    from simplegaussiansplat_tk71_amd import _lib
+
+    lib = _lib.load()
+    b = lib.gcp_pixels_min_workspace_bytes(1919, 1079)
+    assert b % 256 == 0 and 1920 * 1080 * 4 <= b < 1920 * 1080 * 4 + (1 << 20)
+    assert lib.gcp_pixels_min_workspace_bytes(-1, 5) == 0
+    assert lib.gcp_pixels_min_workspace_bytes(1 << 20, 1 << 20) == 0            # beyond the table the call holds
+    assert lib.gcp_pixels_min(None, 0, None, -1, 10, 10, None, None, 0, None, None, 0, None) == 1
+    assert lib.gcp_pixels_min(None, 0, None, 5, 10, 10, None, None, 0, None, None, 0, None) == 1   # no info words
+    assert lib.gcp_pixels_range(None, 0, -1, None, None) == 1
+    F = ck.custom_autograd_grouped_cumprod
+    for name in ("unique", "_create_rects", "_create_alpha_brend", "_mask_zero_T", "_create_alpha_brend_min", "_cat_alpha_brend",
+                 "grad_cumsum", "create_grad_alphabrend_min"):
+        assert callable(getattr(F, name)), name
+    for name in ("create_alpha_brend_min", "create_grad_alphabrend_min", "cat_alpha_brend", "create_rects", "mask_zero_T"):
+        assert name in ck.__all__ and callable(getattr(ck, name))
+    r = torch.zeros(4, 2, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ck.create_alpha_brend_min(r, torch.ones(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ck.create_grad_alphabrend_min(r, torch.ones(4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ck.create_rects(r, r)
+    a, b2 = ck.cat_alpha_brend([torch.ones(2), torch.zeros(3)], [r[:2], r[:3]])   # plain concatenations, any device
+    assert a.tolist() == [1, 1, 0, 0, 0] and b2.shape == (5, 2)
+    t, m = ck.mask_zero_T(torch.tensor([0.5, 0.0, 2.0]))
+    assert t.tolist() == [0.5, 2.0] and m.tolist() == [True, False, True]

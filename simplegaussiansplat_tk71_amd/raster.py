@@ -388,6 +388,17 @@ def finish_boxes(bins, startpoint, endpoint, box_off, values, mode, buffers=None
     return out, keep, dropped
 
 
+def mark_all_kept(mask):
+    """A `!= 0` mask that is known (from the kept count the call read back anyway) to be all ones: `cuda_kernel.mask_tensor` —
+    the reference's `_mask_tensor`, gs_model.py:525-531 — then hands its tensors through instead of indexing each of them."""
+    mask._gcp_all_kept = True
+    return mask
+
+
+def all_kept(mask):
+    return bool(getattr(mask, "_gcp_all_kept", False))
+
+
 def compact_kept(final, keep, dropped=None, begin=0, end=None):
     """[values, mask] of _create_alpha_brend from what `finish_boxes` wrote, rows [begin, end) (the `cutting_number` slice,
     gs_model.py:557-559): ONE device->host read — the kept count, which sizes the result as the reference's `output[mask]`
@@ -417,7 +428,7 @@ def compact_kept(final, keep, dropped=None, begin=0, end=None):
                                               count.data_ptr(), ws.data_ptr(), ws.numel(), st), "gcp_compact_kept_count")
         kept = int(count.item())
         if kept == n:
-            return fin[begin:end], mask
+            return fin[begin:end], mark_all_kept(mask)
         values = torch.empty(kept, dtype=torch.float32, device=dev)
         if kept:
             _lib.check(lib.gcp_compact_kept_write(fin.data_ptr(), kp.data_ptr(), begin, end, values.data_ptr(), ws.data_ptr(), ws.numel(), st),
@@ -717,7 +728,9 @@ def compact_finish(inclusive, self_values, mode, begin=0, end=None, dropped=None
         _lib.check(lib.gcp_compact_finish(inc.data_ptr(), sv.data_ptr(), begin, end, int(mode), values.data_ptr(), keep.data_ptr(),
                                           count.data_ptr(), dropped.data_ptr() if dropped is not None else None, ws.data_ptr(),
                                           ws.numel(), _stream(dev)), "gcp_compact_finish")
-    return values[: int(count.item())], keep.view(torch.bool)
+    kept = int(count.item())
+    mask = keep.view(torch.bool)
+    return values[:kept], (mark_all_kept(mask) if kept == n else mask)
 
 
 def gather_f32(src, index):

@@ -193,8 +193,8 @@ def test_chunk_carry_entry_points_validate_without_a_gpu_and_the_reference_names
     assert lib.gcp_pixels_min(None, 0, None, 5, 10, 10, None, None, 0, None, None, 0, None) == 1   # no info words
     assert lib.gcp_pixels_range(None, 0, -1, None, None) == 1
     F = ck.custom_autograd_grouped_cumprod
-    for name in ("unique", "_create_rects", "_create_alpha_brend", "_mask_zero_T", "_create_alpha_brend_min", "_cat_alpha_brend",
-                 "grad_cumsum", "create_grad_alphabrend_min"):
+    for name in ("unique", "_create_rects", "_create_alpha_brend", "_mask_zero_T", "_mask_tensor", "_sort_tensor", "_create_alpha_brend_min",
+                 "_cat_alpha_brend", "grad_cumsum", "create_grad_alphabrend_min"):
         assert callable(getattr(F, name)), name
     for name in ("create_alpha_brend_min", "create_grad_alphabrend_min", "cat_alpha_brend", "create_rects", "mask_zero_T"):
         assert name in ck.__all__ and callable(getattr(ck, name))

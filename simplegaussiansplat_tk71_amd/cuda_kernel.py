@@ -11,6 +11,15 @@ extension:
   grad_cumsum         <- gs_model.py:716-722
   unique              <- gs_model.py:538-541 (pixel key = y*10000 + x, int32)
 
+and the helpers its chunk loop (`_forward_batch` / `_backward_batch`, gs_model.py:598-663) calls either side of them:
+
+  create_rects                <- gs_model.py:480-482 (_create_rects -> uitility.py:336-366)
+  create_alpha_brend_min      <- gs_model.py:582-586 (_create_alpha_brend_min: torch.unique(dim=0) + scatter_reduce(amin))
+  create_grad_alphabrend_min  <- gs_model.py:724-730
+  cat_alpha_brend, mask_tensor, sort_tensor, mask_zero_T  <- gs_model.py:589-594, :525-531, :517-523, :575-578
+
+all of them also static methods of `custom_autograd_grouped_cumprod` under the reference's names.
+
 Deliberate differences from the reference, all result-preserving:
   * `torch.sort(..., stable=True)`: depth order inside a pixel is carried only by
     sort stability; the reference calls torch.sort without it (gs_model.py:547),

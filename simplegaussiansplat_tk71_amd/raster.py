@@ -472,17 +472,24 @@ class RectBoxes:
 
 
 CUT_SLOT_ROWS = 512   # row records a 4096-pair tile may park in the one-call cut: boxes of 8 columns and more
-CUT_MIN_RECT = 64     # pairs per rectangle its arrays are sized for (a list with smaller boxes takes the step-by-step cut)
+CUT_MIN_RECT = 64     # pairs per rectangle its arrays are sized for
+CUT_SLOT_ROWS_ANY = 2048  # the second attempt: room for every list that is made of boxes at all (rows of 2 pixels on average,
+                          # rectangles of `min_mean_size` pairs: beyond that the list is sorted anyway)
+_cut_sizing = {}  # device index -> (slot_rows, min_rect): what the last list cut there needed, with a margin
 
 
-def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size):
+def _pow2_at_least(x):
+    return 1 << max(0, int(x) - 1).bit_length()
+
+
+def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size, slot_rows=CUT_SLOT_ROWS, min_rect=CUT_MIN_RECT):
     """gcp_rects_cut: rows, rectangles, boxes and the binning's counts with ONE device->host read.  Returns a RectBoxes, None
     (not a list the walk can take: sort) or "retry" (more rows per tile or smaller rectangles than this attempt made room
-    for: the step-by-step cut decides)."""
+    for).  slot_rows / min_rect: the room made — row records per 4096-pair tile, pairs per rectangle."""
     lib = _lib.load()
     m = r.size(0)
     dev = r.device
-    cap = (m - carry_front - carry_back) // CUT_MIN_RECT + carry_front + carry_back + 16
+    cap = (m - carry_front - carry_back) // max(1, int(min_rect)) + carry_front + carry_back + 16
     with _on(dev):
         st = _stream(dev)
         start = torch.empty(cap, 2, dtype=torch.int32, device=dev)
@@ -490,8 +497,8 @@ def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size):
         box_off = torch.empty(cap + 1, dtype=torch.int32, device=dev)
         tile_off = torch.empty(cap + 1, dtype=torch.int32, device=dev)
         info = torch.empty(8, dtype=torch.int32, device=dev)
-        ws = torch.empty(lib.gcp_rects_cut_workspace_bytes(m, carry_front, carry_back, CUT_SLOT_ROWS, cap), dtype=torch.uint8, device=dev)
-        _lib.check(lib.gcp_rects_cut(r.data_ptr(), 1 if i64 else 0, m, carry_front, carry_back, CUT_SLOT_ROWS, cap, start.data_ptr(),
+        ws = torch.empty(lib.gcp_rects_cut_workspace_bytes(m, carry_front, carry_back, slot_rows, cap), dtype=torch.uint8, device=dev)
+        _lib.check(lib.gcp_rects_cut(r.data_ptr(), 1 if i64 else 0, m, carry_front, carry_back, slot_rows, cap, start.data_ptr(),
                                      end.data_ptr(), box_off.data_ptr(), tile_off.data_ptr(), info.data_ptr(), ws.data_ptr(), ws.numel(), st),
                    "gcp_rects_cut")
         n_rows, max_x, max_y, mn, flags, n_rects, k, _ = info.tolist()
@@ -503,6 +510,11 @@ def _cut_rects_once(r, i64, carry_front, carry_back, min_mean_size):
         return "retry"
     if n_rects * min_mean_size > m:
         return None
+    # what this list needed, with a margin, for the next list cut on this device (a training loop's lists resemble each other)
+    body = max(1, m - carry_front - carry_back)
+    tiles = (m + 4095) // 4096
+    _cut_sizing[dev.index] = (min(CUT_SLOT_ROWS_ANY, max(CUT_SLOT_ROWS, _pow2_at_least(5 * n_rows // (4 * max(1, tiles))))),
+                              max(int(min_mean_size), min(CUT_MIN_RECT, _pow2_at_least(body // max(1, n_rects)) // 4)))
     return RectBoxes(start[:n_rects], end[:n_rects], box_off[: n_rects + 1], int(max_x), int(max_y), tile_off[: n_rects + 1], int(k))
 
 
@@ -515,9 +527,11 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0, carry_at_end=False, one
     are allowed for on top.
 
     Default: the whole cut AND the binning's counting pass in one call (gcp_rects_cut) with ONE device->host read and 2.5 B of
-    scratch per pair — sized for what the reference's lists are (rows of 8 pixels and more, rectangles of 64 pairs and more
-    on average).  A list of smaller boxes takes the step-by-step cut (three reads, 14 B of scratch per pair; one_call=False
-    forces it)."""
+    scratch per pair — sized for what the last list cut on the device needed (at first: rows of 8 pixels and more, rectangles
+    of 64 pairs and more on average).  A list of smaller boxes than that repeats the call once with room for anything that
+    is boxes at all (rows of 2 pixels, rectangles of `min_mean_size` pairs: 8 B of scratch per pair + 3.5 B in the box
+    arrays), and the next list starts from what this one needed.  one_call=False forces the step-by-step cut (three reads,
+    14 B of scratch per pair)."""
     # int64 lists — what the reference's own make_rect_points_parallel returns (uitility.py:336-366) — are read as they are
     i64 = isinstance(rects, torch.Tensor) and rects.dtype == torch.int64
     r = _dev_tensor(rects, "rects", torch.int64 if i64 else torch.int32, (2,))
@@ -530,9 +544,14 @@ def rects_to_boxes(rects, min_mean_size=8, carry_rows=0, carry_at_end=False, one
     cut = lib.gcp_rects_rows_i64 if i64 else lib.gcp_rects_rows
     carry_rows = min(max(int(carry_rows), 0), m)
     if one_call:
-        out = _cut_rects_once(r, i64, 0 if carry_at_end else carry_rows, carry_rows if carry_at_end else 0, min_mean_size)
-        if not isinstance(out, str):
-            return out
+        # first with the room the last list cut on this device needed (default: rows of 8 pixels, rectangles of 64 pairs),
+        # then — a list of smaller boxes — with room for anything that is boxes at all; only then step by step
+        cf, cb = (0, carry_rows) if carry_at_end else (carry_rows, 0)
+        sizing = _cut_sizing.get(dev.index, (CUT_SLOT_ROWS, CUT_MIN_RECT))
+        for slot_rows, min_rect in (sizing, (CUT_SLOT_ROWS_ANY, max(1, int(min_mean_size)))):
+            out = _cut_rects_once(r, i64, cf, cb, min_mean_size, slot_rows, min_rect)
+            if not isinstance(out, str):
+                return out
     cap = min(carry_rows + lib.gcp_rects_rows_capacity(m - carry_rows), m + 1)
     with torch.cuda.device(dev):
         st = _stream(dev)

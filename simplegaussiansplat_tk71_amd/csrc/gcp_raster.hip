@@ -1113,6 +1113,28 @@ __device__ __forceinline__ void walk_fold(const WalkBatch& b, float* __restrict_
   }
 }
 
+// Which tile a block of the walk takes.  Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8), and tiles
+// that share cache lines should share an L2 (see the kernel).  xcd_remap 1: XCD x takes the x-th contiguous eighth of the
+// tiles — a band of tile rows.  xcd_remap >= 2: STRIPES of 2^(xcd_remap - 2) tile rows dealt round-robin to the XCDs, so that
+// every XCD holds stripes from all over the image: a scene whose Gaussians crowd one region (bands: the XCDs of that region
+// do most of the work while the others idle) is spread evenly, and all but the lines that straddle a stripe edge still
+// share an L2.  0: tile = block.
+__device__ __forceinline__ int walk_tile(unsigned b, int n_tiles, int tiles_x, int xcd_remap) {
+  if (xcd_remap < 2) return (int)sort_chunk(b, n_tiles, xcd_remap);
+  const int sh = xcd_remap - 2;                  // log2 of the tile rows per stripe
+  const int x = (int)(b & 7u), j = (int)(b >> 3);  // XCD, and the block's number on it
+  const int per_stripe = tiles_x << sh;
+  const int stripe = (j / per_stripe) * 8 + x, within = j % per_stripe;
+  const int tile = stripe * per_stripe + within;
+  return tile < n_tiles ? tile : -1;
+}
+inline unsigned walk_grid(int n_tiles, int tiles_x, int xcd_remap) {
+  if (xcd_remap < 2) return sort_grid(n_tiles, xcd_remap);
+  const int per_stripe = tiles_x << (xcd_remap - 2);
+  const int stripes = (n_tiles + per_stripe - 1) / per_stripe;
+  return (unsigned)(((stripes + 7) / 8) * 8 * per_stripe);
+}
+
 template <int MODE, bool WIDE, int OUT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 // (pinned to eight waves per SIMD the byte-offset form fits 63 VGPRs without a spill — and runs no faster: 0.62 ms either way)
 __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
@@ -1131,9 +1153,10 @@ __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendAr
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // A box is one contiguous run of the pair arrays (row-major, uitility.py:336-366) but lies across up to 2 x 2 tiles: with
   // blocks dealt round-robin over the XCDs its pieces would be written from different L2s and reach memory as partial
-  // lines (measured: 2.6x the algorithmic bytes).  XCD x therefore takes the x-th contiguous eighth of the tiles
-  // (row-major = a band of tile rows): horizontal and, but for the band edges, vertical neighbours share an L2.
-  const int tile = (int)sort_chunk(blockIdx.x, n_tiles, xcd_remap);
+  // lines (measured: 2.6x the algorithmic bytes).  An XCD therefore takes whole tile ROWS (walk_tile): the two pieces of a
+  // box row, which share cache lines, always meet in one L2; only the line a box's rows 15 | 16 of a tile-row pair straddle
+  // is written from two.
+  const int tile = walk_tile(blockIdx.x, n_tiles, a.tiles_x, xcd_remap);
   if (tile < 0) return;
   const int tile_x0 = (tile % a.tiles_x) * kTileW, tile_y0 = (tile / a.tiles_x) * kTileH;
   constexpr int kUnit = WIDE ? 1 : 4;
@@ -2040,7 +2063,10 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   if (n_gauss == 0) return GCP_OK;
   if (!start_xy || !end_xy || !tile_list || !box_off || !x || !out || x == out) return GCP_ERR_INVALID_ARGUMENT;
   const TileGrid tg = tile_grid(width, height);
-  static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 1; }();
+  // stripes of one tile row dealt round-robin to the XCDs (walk_tile): as fast as contiguous bands on a scene that fills the
+  // image evenly (0.65 against 0.64 ms at cfg3), and 18 % / 43 % faster where the Gaussians crowd the middle (sigma = extent / 4,
+  // / 8: the bands of the crowded region worked while the others idled) — profiles/r04_walk_experiments.md
+  static const int xcd_remap = [] { const char* e = getenv("GCP_WALK_XCD"); return (e && *e) ? atoi(e) : 2; }();
   // pair positions as 32-bit byte offsets while the list is no longer than 2^30 pairs (GCP_WALK_WIDE=1 forces the other form)
   const char* fw = getenv("GCP_WALK_WIDE");  // read per call: the tests switch it inside one process
   const bool wide = (fw && *fw && atoi(fw) != 0) || n_pairs > (1LL << 30);
@@ -2049,7 +2075,7 @@ static int walk_impl(const int32_t* start_xy, const int32_t* end_xy, int64_t n_g
   if ((int64_t)width + 1 >= (wide ? (1LL << 24) : (1LL << 22))) return GCP_ERR_INVALID_ARGUMENT;
   const int out_mode = keep ? kWalkFinal : (dropped_per_tile ? kWalkCount : kWalkInclusive);
   const int n_tiles = tg.tx * tg.ty;
-  const dim3 grid(sort_grid(n_tiles, xcd_remap)), block(kWalkThreads);
+  const dim3 grid(walk_grid(n_tiles, tg.tx, xcd_remap)), block(kWalkThreads);
 #if GCP_WALK_DENSE
   const int n_blocks = (n_tiles + 3) / 4;
   const dim3 dgrid(sort_grid(n_blocks, xcd_remap));

@@ -1,0 +1,49 @@
+"""create_alpha_brend / the Function's binning on scenes of the cfg3 pair count whose Gaussians crowd the image centre (normal with
+sigma = extent / s): tile lists far deeper than the mean.   python tools/clustered_bench.py [s ...]   (0 = uniform)"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cuda_kernel as ck  # noqa: E402
+from simplegaussiansplat_tk71_amd import raster, synthetic  # noqa: E402
+from tools.wrapper_bench import timeit  # noqa: E402
+
+dev = torch.device("cuda", 0)
+W, H = 1919, 1079
+for s in [float(a) for a in sys.argv[1:]] or [0.0, 4.0, 8.0, 16.0]:
+    sc = synthetic.make_scene(1_000_000, W, H, 80.0, seed=0, device=dev)
+    if s > 0:  # same boxes, centres pulled towards the middle
+        g = torch.Generator(device=dev).manual_seed(7)
+        half = (sc["end"] - sc["start"]) // 2
+        cx = (torch.randn(sc["start"].size(0), device=dev, generator=g) * (W / s) + W / 2).round().clamp(0, W).to(torch.int32)
+        cy = (torch.randn(sc["start"].size(0), device=dev, generator=g) * (H / s) + H / 2).round().clamp(0, H).to(torch.int32)
+        c = torch.stack([cx, cy], 1)
+        lim = torch.tensor([W, H], dtype=torch.int32, device=dev)
+        sc["start"] = (c - half).clamp(min=0)
+        sc["end"] = torch.minimum(c + half, lim)
+    rects, owner = raster.expand_rects(sc["start"], sc["end"], W, H, with_gaussian=True)
+    m = rects.size(0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    anti = 1.0 - sc["opacity"].reshape(-1)[owner.long()] * torch.rand(m, device=dev, generator=g)
+    del owner
+    bins = raster.bin_tiles(sc["start"], sc["end"], W, H)
+    depth = (bins.tile_start[1:] - bins.tile_start[:-1])
+    out = {"sigma_divisor": s, "pairs": m, "tile_entries": bins.n_tile_pairs, "deepest_tile_list": int(depth.max()), "mean_tile_list": float(depth.float().mean())}
+    boff = raster.box_offsets(sc["start"], sc["end"], W, H)
+    out["walk_ms"] = timeit(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, anti, 0), 5, 2)
+    near1 = 1.0 - 1e-5 * torch.rand(m, device=dev, generator=g)   # products that never underflow: nothing is dropped, the depth alone is left
+    out["walk_no_drops_ms"] = timeit(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, near1, 0), 5, 2)
+    zeros = anti.clone()
+    zeros[::3] = 0.0                                              # nearly every pair behind an opaque one: dropped, whatever the depth
+    out["walk_mostly_dropped_ms"] = timeit(lambda: raster.finish_boxes(bins, sc["start"], sc["end"], boff, zeros, 0), 5, 2)
+    del near1, zeros
+    out["create_alpha_brend_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod"), 5, 2)
+    out["sort_route_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(W, H), route="sort"), 3, 1)
+    T = ck.create_alpha_brend(rects, anti, "cumprod")[0]
+    out["dropped"] = int(m - T.numel())
+    print(json.dumps(out), flush=True)
+    del rects, anti, sc, bins, boff, T
+    torch.cuda.empty_cache()

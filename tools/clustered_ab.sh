@@ -10,6 +10,6 @@ import json, sys
 for line in open(sys.argv[2]):
     if line.startswith("{"):
         d = json.loads(line)
-        print(f"{sys.argv[1]:10s} sigma/{d['sigma_divisor']:<4} deepest {d['deepest_tile_list']:6d}  walk {d['walk_ms']:.3f} ms (no drops {d['walk_no_drops_ms']:.3f}, mostly dropped {d['walk_mostly_dropped_ms']:.3f})  call {d['create_alpha_brend_ms']:.3f} ms")
+        print(f"{sys.argv[1]:10s} sigma/{d['sigma_divisor']:<4} deepest {d['deepest_tile_list']:6d}  walk {d['walk_ms']:.3f} ms (no drops {d['walk_no_drops_ms']:.3f}, mostly dropped {d['walk_mostly_dropped_ms']:.3f})  call {d['create_alpha_brend_ms']:.3f} ms  blend fwd {d['blend_forward_ms']:.3f} bwd {d['blend_backward_ms']:.3f}")
 PY
 done

@@ -44,6 +44,13 @@ for s in [float(a) for a in sys.argv[1:]] or [0.0, 4.0, 8.0, 16.0]:
     out["sort_route_ms"] = timeit(lambda: ck.create_alpha_brend(rects, anti, "cumprod", image_size=(W, H), route="sort"), 3, 1)
     T = ck.create_alpha_brend(rects, anti, "cumprod")[0]
     out["dropped"] = int(m - T.numel())
+    # the fused Function's kernels on the same scene (row f1): one block per tile as well
+    mean = ((sc["start"] + sc["end"]) // 2).to(torch.int32)
+    img, ckpt = raster.blend_forward(bins, sc["start"], sc["end"], mean, sc["vinv"], sc["opacity"], sc["l_d"], with_checkpoints=True)
+    gimg = torch.randn_like(img)
+    out["blend_forward_ms"] = timeit(lambda: raster.blend_forward(bins, sc["start"], sc["end"], mean, sc["vinv"], sc["opacity"], sc["l_d"], with_checkpoints=True), 5, 2)
+    out["blend_backward_ms"] = timeit(lambda: raster.blend_backward(bins, sc["start"], sc["end"], mean, sc["vinv"], sc["opacity"], sc["l_d"], ckpt, gimg), 5, 2)
+    del img, ckpt, gimg, mean
     print(json.dumps(out), flush=True)
     del rects, anti, sc, bins, boff, T
     torch.cuda.empty_cache()

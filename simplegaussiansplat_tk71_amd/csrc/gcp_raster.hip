@@ -1159,6 +1159,31 @@ inline unsigned walk_grid(int n_tiles, int tiles_x, int xcd_remap) {
   return (unsigned)(((stripes + 7) / 8) * 8 * per_stripe);
 }
 
+// A wave all of whose 64 pixels have reached a product of exactly 0 (cumprod: it stays 0 — behind an opaque pair, or where the
+// product has underflowed, hundreds of layers deep) has nothing left to compute: every further pair of its strip is dropped
+// whatever its value.  The rest of the tile's list then costs it one byte per pair — the pair's `keep` byte is cleared and the
+// drop counted — instead of a 4-byte load, a multiplication and a 4-byte store (whose result nobody reads: the compaction
+// that follows moves kept values only).  Scenes that crowd one region drop a large share of their pairs this way.
+template <bool WIDE>
+__device__ __forceinline__ void walk_dead(unsigned long long hits, const int4* __restrict__ ent, unsigned lane_bits, int ly, int lxo,
+                                          int* __restrict__ dropped, unsigned char* __restrict__ keep) {
+  while (hits) {
+    const int k = __builtin_ctzll(hits);
+    hits &= hits - 1ull;
+    const int4 e = ent[k];
+#if GCP_TILE_SX == 4
+    const bool in = ((unsigned)e.z & lane_bits) == lane_bits;
+#elif GCP_TILE_SX == 5
+    const bool in = (((unsigned)e.z & lane_bits) != 0u) & (((unsigned)e.w & (1u << ly)) != 0u);
+#else
+    const bool in = ((((int)(threadIdx.x & 32) ? (unsigned)e.w : (unsigned)e.z) & lane_bits) != 0u);
+#endif
+    const unsigned o = (unsigned)e.x + (unsigned)lxo + __umul24((unsigned)ly, (unsigned)e.y);
+    if (in) keep[WIDE ? o : (o >> 2)] = 0;
+    walk_count_dropped<WIDE>(in, in ? o : 0u, dropped);
+  }
+}
+
 template <int MODE, bool WIDE, int OUT>  // MODE 0 cumprod, 1 cumsum, 2 reverse cumsum; WIDE: more than 2^30 pairs
 // (pinned to eight waves per SIMD the byte-offset form fits 63 VGPRs without a spill — and runs no faster: 0.62 ms either way)
 __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendArgs a, const int* __restrict__ box_off,
@@ -1233,6 +1258,10 @@ __global__ __launch_bounds__(kWalkThreads) void k_pairs_scan_boxes(const BlendAr
     }
     __syncthreads();
     unsigned long long hits = uniform64(s_hits[w]);
+    if (MODE == 0 && OUT == kWalkFinal && hits && __ballot(acc != 0.0f) == 0ull) {  // wave-uniform, decided once per round
+      walk_dead<WIDE>(hits, s_ent, lane_bits, ly, lxo, dropped, keep);
+      continue;
+    }
     // two batches in flight: the loads of the next one are issued before the stores of the one in hand, so that waiting
     // for loaded values (in-order counter) never waits for the stores just issued
     if (hits) {

@@ -711,6 +711,10 @@ __global__ __launch_bounds__(256) void k_blend_fwd(const BlendArgs a, float* __r
           ck[(i64)((base - first + e0) / kCkpt) * 256] = T;
         }
         unsigned hits = (unsigned)(hits64 >> (sub * kCkpt)) & (unsigned)((1ull << kCkpt) - 1ull);
+        // wave-uniform: every pixel of the strip is behind an exact zero (an opaque layer, or a product that underflowed
+        // hundreds of layers deep) — T stays 0 and nothing more reaches the image: the rest of the list costs this wave its
+        // checkpoints only
+        if (__ballot(T != 0.0f) == 0ull) hits = 0u;
         while (hits) {
           const int k = e0 + __builtin_ctz(hits);
           hits &= hits - 1;
@@ -905,7 +909,15 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
     };
     // two copies of the loop, chosen per chunk: the common one carries nothing of the other's (with one loop and the test inside,
     // the common path ran 2-6 % slower after the slow one grew its per-group product)
-    if (slow) walk_chunk(std::true_type{}); else walk_chunk(std::false_type{});
+    if (__ballot(T_start != 0.0f) == 0ull) {
+      // every pixel of the strip enters the chunk behind an exact zero: T_k = 0 throughout, every term is 0 and R does not
+      // move — the wave hands the fold its zeros and goes on (a scene that crowds one region has half its pairs there)
+      for (unsigned hz = hits; hz; hz &= hz - 1) row_slot[__builtin_ctz(hz) * kPartStride] = 0.0f;
+    } else if (slow) {
+      walk_chunk(std::true_type{});
+    } else {
+      walk_chunk(std::false_type{});
+    }
     __syncthreads();
     // one thread per entry: add the 16 pixel rows in fixed order, write the entry's Gaussian-major slot
     for (int j = threadIdx.x; j < cnt; j += 256) {

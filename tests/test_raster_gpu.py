@@ -463,6 +463,46 @@ def test_gaussians_behind_an_opaque_stack_get_accurate_gradients(device):
         assert float(rel.max()) < 1e-3, (name, float(rel.max()), int(rel.argmax()))
 
 
+def test_layers_behind_an_exactly_opaque_layer_add_nothing_and_get_zero_gradients(device):
+    """A flat layer of opacity exactly 1 (Λ = 0: g = 1 everywhere, 1 - αG = 0) over the upper half of a 32 x 48 image, 70 layers
+    behind it, 20 in front: every pixel of the upper tiles' strips is behind an exact zero — the forward skips the rest of
+    their lists and the backward writes their zeros without evaluating them (§5 item 9) — while the lower half goes on
+    through all 91 layers; both against the dense oracle, the hidden layers' gradients exactly 0 in the covered tiles."""
+    from oracle import dense_render as dr
+
+    w, h = 31, 47
+    n_front, n_back = 20, 70
+    n = n_front + 1 + n_back
+    g = torch.Generator().manual_seed(11)
+    start = torch.zeros(n, 2, dtype=torch.int32)
+    end = torch.tensor([[w, h]], dtype=torch.int32).repeat(n, 1)
+    end[n_front] = torch.tensor([w, 15])                      # the opaque layer: the upper tile row only
+    mean = torch.stack([torch.randint(4, 28, (n,), generator=g), torch.randint(4, 44, (n,), generator=g)], 1).to(torch.int32)
+    vinv = (torch.eye(2) * 3e-3).repeat(n, 1, 1)
+    vinv[n_front] = 0.0
+    opacity = 0.05 + 0.5 * torch.rand(n, 1, generator=g)
+    opacity[n_front] = 1.0
+    sc = {"start": start, "end": end, "mean": mean, "vinv": vinv, "opacity": opacity, "l_d": 0.1 + torch.rand(n, 3, generator=g),
+          "boxsize": torch.prod((end - start + 1).long(), 1), "width": w, "height": h, "wimg": torch.randn(h + 1, w + 1, 3, generator=g)}
+    img, gv, go, gl = _apply(device, sc)
+    i64, gv64, go64, gl64 = dr.render_with_grads(start, end, mean, vinv, opacity, sc["l_d"], w, h, sc["wimg"])
+    torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    for name, got, want in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
+        got, want = got.double().reshape(n, -1), want.reshape(n, -1)
+        scale = want.abs().max().item()
+        assert float((got - want).abs().max()) <= 2e-5 * (1.0 + scale), name
+    # the same scene with the opaque layer over the WHOLE image: nothing behind it reaches the image or gets a gradient
+    end2 = end.clone()
+    end2[n_front] = torch.tensor([w, h])
+    sc2 = dict(sc, end=end2, boxsize=torch.prod((end2 - start + 1).long(), 1))
+    img2, gv2, go2, gl2 = _apply(device, sc2)
+    sc3 = {k: (v[: n_front + 1] if torch.is_tensor(v) and v.size(0) == n else v) for k, v in sc2.items()}
+    img3, gv3, go3, gl3 = _apply(device, sc3)
+    assert torch.equal(img2, img3)
+    assert float(go2[n_front + 1:].abs().max()) == 0.0 and float(gv2[n_front + 1:].abs().max()) == 0.0 and float(gl2[n_front + 1:].abs().max()) == 0.0
+    assert torch.equal(go2[: n_front + 1], go3) and torch.equal(gl2[: n_front + 1], gl3) and torch.equal(gv2[: n_front + 1], gv3)
+
+
 def _stack_scene(n_layers, opacity_lo, opacity_hi, seed, w=15, h=15):
     """`n_layers` wide Gaussians over one 16x16 tile: every pixel's list is n_layers deep."""
     g = torch.Generator().manual_seed(seed)

@@ -12,6 +12,15 @@ from tests.util import TOL, make_scene
 pytestmark = pytest.mark.gpu
 
 
+def _boxes_to_rects(start, end):
+    """uitility.py:336-366 on the host: box after box, row-major inside a box, int32 [M,2] (x, y)."""
+    rows = []
+    for (x0, y0), (x1, y1) in zip(start.tolist(), end.tolist()):
+        ys, xs = torch.meshgrid(torch.arange(y0, y1 + 1), torch.arange(x0, x1 + 1), indexing="ij")
+        rows.append(torch.stack((xs.flatten(), ys.flatten()), 1))
+    return torch.cat(rows).to(torch.int32)
+
+
 def _rects_of(sc, device):
     from simplegaussiansplat_tk71_amd import raster
 
@@ -854,6 +863,43 @@ def test_one_call_cut_with_carry_rows_and_on_lists_it_has_no_room_for(device):
     neg[17, 1] = -4
     with pytest.raises(RuntimeError, match="negative"):
         raster._cut_rects_once(neg, False, 0, 0, 8)
+
+
+def test_pairs_behind_an_exact_zero_are_dropped_without_being_read(device):
+    """90 boxes over a 48 x 40 image; box 20's factors are all 0 over the upper 16 rows (whole tiles: every strip there is behind
+    an exact zero from then on — the walk clears the rest of their `keep` bytes without loading a value, §5 item 9), 0 at scattered
+    pixels elsewhere; against the literal CPU statement, every route, with a chunked call's carry rows in front as well."""
+    import cuda_kernel as ck
+    from oracle import wrappers as ow
+
+    w, h, n = 47, 39, 90
+    g = torch.Generator().manual_seed(13)
+    start = torch.zeros(n, 2, dtype=torch.int32)
+    end = torch.tensor([[w, h]], dtype=torch.int32).repeat(n, 1)
+    small = torch.arange(n) % 3 == 1                       # every third box a small one somewhere
+    cx, cy = torch.randint(0, w - 8, (n,), generator=g), torch.randint(0, h - 8, (n,), generator=g)
+    start[small] = torch.stack([cx, cy], 1)[small].to(torch.int32)
+    end[small] = start[small] + 7
+    rects = _boxes_to_rects(start, end).to(device)
+    anti = (1.0 - 0.5 * torch.rand(rects.size(0), generator=g))
+    off = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.long), torch.prod((end - start + 1).long(), 1)]), 0)
+    b20 = slice(int(off[20]), int(off[21]))
+    rows = rects[b20, 1].cpu()
+    anti[b20] = torch.where(rows <= 15, torch.zeros(()), anti[b20])
+    anti[::41] = 0.0
+    want_v, want_m, _, _ = ow.create_alpha_brend(rects.cpu(), anti, "cumprod")
+    assert int((~want_m).sum()) > rects.size(0) // 4            # a good part of the list lies behind the zeros
+    for route in ("boxes", "sort"):
+        v, m = ck.create_alpha_brend(rects, anti.to(device), "cumprod", image_size=(w, h) if route == "sort" else None, route=route)
+        assert torch.equal(m.cpu(), want_m), route
+        assert (v.cpu() - want_v).abs().max().item() <= TOL, route
+    prep = ck.PreparedRects(rects)
+    v, m = ck.create_alpha_brend(prep, anti.to(device), "cumprod")
+    assert torch.equal(m.cpu(), want_m) and (v.cpu() - want_v).abs().max().item() <= TOL
+    # sums are not products: a zero stops nothing there
+    want_s, want_sm, _, _ = ow.create_alpha_brend(rects.cpu(), anti, "cumsum")
+    s_, sm = ck.create_alpha_brend(rects, anti.to(device), "cumsum")
+    assert torch.equal(sm.cpu(), want_sm) and torch.allclose(s_.cpu(), want_s, atol=1e-4, rtol=1e-5)
 
 
 def test_one_call_cut_makes_room_for_small_boxes_and_remembers_what_a_list_needed(device):

@@ -199,30 +199,54 @@ __global__ __launch_bounds__(256) void k_tile_count(const int* start, const int*
 
 // `capacity` / `info` (capture-safe binning, gcp_bin_tiles): a Gaussian whose entries do not fit below `capacity` is
 // left out together with everything behind it; info[0] = entries actually listed, info[1] = 1 if anything was left out.
-__global__ void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
-                            const int* off, unsigned* key, unsigned* val, i64 capacity, int* info,
-                            const unsigned long long* total64) {
+// A box over many tiles (a background splat: 8 100 of them at 1080p) is emitted by its whole wave, lane l taking entries l,
+// l + 64, ... — one thread writing them all kept the launch waiting (0.16 -> 0.49 ms for twenty such boxes).
+constexpr int kEmitWide = 128;
+__global__ __launch_bounds__(256) void k_tile_emit(const int* start, const int* end, i64 n, int W, int H, int tiles_x,
+                                                   const int* off, unsigned* key, unsigned* val, i64 capacity, int* info,
+                                                   const unsigned long long* total64) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
+  const int lane = threadIdx.x & 63;
+  bool live = g < n;
   if (info) {
     if (*total64 > 0x7fffffffull) {  // the int32 prefix sums have wrapped: nothing can be listed
       if (g == 0) { info[0] = 0; info[1] = 1; }
       return;
     }
-    const i64 lo = off[g], hi = off[g + 1];
-    if (g == 0 && (i64)off[n] <= capacity) { info[0] = off[n]; info[1] = 0; }
-    if (lo <= capacity && hi > capacity) { info[0] = (int)lo; info[1] = 1; }  // the one Gaussian that straddles the bound
-    if (hi > capacity) return;
-  }
-  Box b;
-  if (!load_box(start, end, g, W, H, b)) return;
-  int e = off[g];
-  for (int ty = b.y0 >> kTileSY; ty <= (b.y1 >> kTileSY); ++ty)
-    for (int tx = b.x0 >> kTileSX; tx <= (b.x1 >> kTileSX); ++tx) {
-      key[e] = (unsigned)(ty * tiles_x + tx);
-      val[e] = (unsigned)g;
-      ++e;
+    if (live) {
+      const i64 lo = off[g], hi = off[g + 1];
+      if (g == 0 && (i64)off[n] <= capacity) { info[0] = off[n]; info[1] = 0; }
+      if (lo <= capacity && hi > capacity) { info[0] = (int)lo; info[1] = 1; }  // the one Gaussian that straddles the bound
+      if (hi > capacity) live = false;
     }
+  }
+  Box b = {0, 0, -1, -1};
+  if (live) live = load_box(start, end, g, W, H, b);
+  const int tx0 = b.x0 >> kTileSX, ty0 = b.y0 >> kTileSY;
+  const int ntx = live ? (b.x1 >> kTileSX) - tx0 + 1 : 0, nty = live ? (b.y1 >> kTileSY) - ty0 + 1 : 0;
+  const int e0 = live ? off[g] : 0;
+  const bool wide = ntx * nty >= kEmitWide;
+  if (live && !wide) {
+    int e = e0;
+    for (int ty = ty0; ty < ty0 + nty; ++ty)
+      for (int tx = tx0; tx < tx0 + ntx; ++tx) {
+        key[e] = (unsigned)(ty * tiles_x + tx);
+        val[e] = (unsigned)g;
+        ++e;
+      }
+  }
+  for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1ull) {  // wave-uniform: one wide box at a time
+    const int owner = __builtin_ctzll(todo);
+    const int wtx0 = __builtin_amdgcn_readlane(tx0, owner), wty0 = __builtin_amdgcn_readlane(ty0, owner);
+    const int wntx = __builtin_amdgcn_readlane(ntx, owner), wcount = wntx * __builtin_amdgcn_readlane(nty, owner);
+    const int we0 = __builtin_amdgcn_readlane(e0, owner);
+    const unsigned wg = (unsigned)(g - lane + owner);
+    for (int i = lane; i < wcount; i += 64) {
+      const int ty = i / wntx, tx = i - ty * wntx;
+      key[we0 + i] = (unsigned)((wty0 + ty) * tiles_x + wtx0 + tx);
+      val[we0 + i] = wg;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -945,12 +969,17 @@ __global__ __launch_bounds__(256) void k_blend_bwd(const BlendArgs a, const int*
   }
 }
 
-// per Gaussian: sum its tile slots in order, expand the moments into the four gradients
-__global__ void k_grad_reduce(const float* __restrict__ partial, const int* __restrict__ tile_off,
-                              const int* __restrict__ tile_start, int n_tiles, const float* __restrict__ vinv, i64 n,
-                              i64 capacity, float* grad_mean, float* grad_vinv, float* grad_opacity, float* grad_l) {
+// per Gaussian: sum its tile slots in order, expand the moments into the four gradients.
+// A Gaussian whose box covers many tiles (a background splat over the whole frame: 8 100 slots of 9 values) is not left to one
+// thread — 73 000 dependent loads, 1.1 ms for twenty of them while the rest of the launch takes 0.04 — but summed by its whole
+// wave: lane l takes slots e0 + l, e0 + l + 64, ... in order, and the 64 partial sums are added in a fixed butterfly.  Which
+// Gaussians go that way depends on their slot count alone, so the result is the same from run to run.
+constexpr int kReduceWide = 128;  // tile slots from which a Gaussian is summed by the wave
+__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ partial, const int* __restrict__ tile_off,
+                                                     const int* __restrict__ tile_start, int n_tiles, const float* __restrict__ vinv, i64 n,
+                                                     i64 capacity, float* grad_mean, float* grad_vinv, float* grad_opacity, float* grad_l) {
   const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
+  const int lane = threadIdx.x & 63;
   float r[kGradVals];
 #pragma unroll
   for (int v = 0; v < kGradVals; ++v) r[v] = 0.0f;
@@ -959,12 +988,36 @@ __global__ void k_grad_reduce(const float* __restrict__ partial, const int* __re
   // capacity the Gaussians that fit; nothing at all when the int32 prefix sums wrapped at > 2^31 entries — the offsets
   // behind the wrap are negative or decreasing, and even the ones before it point at slots nobody wrote).  Zeros otherwise.
   const i64 listed = min((i64)tile_start[n_tiles], capacity);
-  const i64 e0 = tile_off[g];
-  i64 e1 = tile_off[g + 1];
-  if (e0 < 0 || e1 < e0 || e1 > listed) e1 = e0 < 0 ? 0 : e0;
-  for (i64 e = (e0 < 0 ? 0 : e0); e < e1; ++e)
+  i64 e0 = 0, e1 = 0;
+  if (g < n) {
+    e0 = tile_off[g];
+    e1 = tile_off[g + 1];
+    if (e0 < 0 || e1 < e0 || e1 > listed) e1 = e0 < 0 ? 0 : e0;
+    if (e0 < 0) e0 = 0;
+  }
+  const bool wide = e1 - e0 >= kReduceWide;
+  if (!wide) {
+    for (i64 e = e0; e < e1; ++e)
 #pragma unroll
-    for (int v = 0; v < kGradVals; ++v) r[v] += partial[e * kGradVals + v];
+      for (int v = 0; v < kGradVals; ++v) r[v] += partial[e * kGradVals + v];
+  }
+  for (unsigned long long todo = __ballot(wide); todo; todo &= todo - 1ull) {  // wave-uniform: one wide Gaussian at a time
+    const int owner = __builtin_ctzll(todo);
+    const i64 f0 = (i64)__builtin_amdgcn_readlane((int)e0, owner), f1 = (i64)__builtin_amdgcn_readlane((int)e1, owner);  // (entries < 2^31)
+    float p[kGradVals];
+#pragma unroll
+    for (int v = 0; v < kGradVals; ++v) p[v] = 0.0f;
+    for (i64 e = f0 + lane; e < f1; e += 64)
+#pragma unroll
+      for (int v = 0; v < kGradVals; ++v) p[v] += partial[e * kGradVals + v];
+#pragma unroll
+    for (int v = 0; v < kGradVals; ++v) {
+      float t = p[v];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);  // a fixed butterfly: every lane ends with the same sum
+      if (lane == owner) r[v] = t;
+    }
+  }
+  if (g >= n) return;
   const float A = vinv[4 * g], B = vinv[4 * g + 1], C = vinv[4 * g + 2], D = vinv[4 * g + 3];
   grad_opacity[g] = r[0];
   grad_l[3 * g] = r[1]; grad_l[3 * g + 1] = r[2]; grad_l[3 * g + 2] = r[3];

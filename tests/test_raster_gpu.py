@@ -503,6 +503,45 @@ def test_layers_behind_an_exactly_opaque_layer_add_nothing_and_get_zero_gradient
     assert torch.equal(go2[: n_front + 1], go3) and torch.equal(gl2[: n_front + 1], gl3) and torch.equal(gv2[: n_front + 1], gv3)
 
 
+def test_boxes_over_hundreds_of_tiles_among_small_ones(device):
+    """Background splats: six Gaussians whose boxes cover a whole 304 x 208 image (19 x 13 = 247 tiles each) spread through 600
+    small ones.  Their (tile, Gaussian) entries are emitted, and their 247 gradient slots summed, by a whole wave instead of one
+    thread (k_tile_emit, k_grad_reduce); the tile lists against the sort the reference would do, image and gradients against
+    the dense oracle."""
+    from oracle import dense_render as dr
+    from simplegaussiansplat_tk71_amd import raster
+
+    w, h = 303, 207
+    sc = make_scene(606, w, h, 6, seed=17)
+    big = torch.arange(0, 606, 101)
+    sc["start"][big] = 0
+    sc["end"][big] = torch.tensor([w, h], dtype=torch.int32)
+    sc["opacity"][big] = 0.05
+    sc["vinv"][big] = torch.eye(2) * 1e-4
+    sc["boxsize"] = torch.prod((sc["end"] - sc["start"] + 1).long(), 1)
+    bins = raster.bin_tiles(sc["start"].to(device), sc["end"].to(device), w, h)
+    # reference order: (tile, Gaussian) pairs sorted by tile, Gaussians ascending inside a tile
+    tx0, ty0 = sc["start"][:, 0] // 16, sc["start"][:, 1] // 16
+    tx1, ty1 = sc["end"][:, 0] // 16, sc["end"][:, 1] // 16
+    want = []
+    for g in range(606):
+        for ty in range(int(ty0[g]), int(ty1[g]) + 1):
+            for tx in range(int(tx0[g]), int(tx1[g]) + 1):
+                want.append((ty * bins.tiles_x + tx, g))
+    want.sort()
+    assert bins.n_tile_pairs == len(want)
+    assert bins.tile_list.cpu().tolist() == [g for _, g in want]
+    img, gv, go, gl = _apply(device, sc)
+    i64, gv64, go64, gl64 = dr.render_with_grads(sc["start"], sc["end"], sc["mean"], sc["vinv"], sc["opacity"], sc["l_d"], w, h, sc["wimg"])
+    torch.testing.assert_close(img.double(), i64, atol=TOL, rtol=TOL)
+    for name, got, want64 in (("opacity", go, go64), ("vinv", gv, gv64), ("l_d", gl, gl64)):
+        got, want64 = got.double().reshape(606, -1), want64.reshape(606, -1)
+        # a background splat's gradient is a sum over 63 000 pixels: the bound is relative to the sum of its |terms|, which
+        # the largest component over-estimates by little here
+        scale = want64.abs().max(1, keepdim=True).values
+        assert bool(((got - want64).abs() <= 1e-4 * (1.0 + scale)).all()), name
+
+
 def _stack_scene(n_layers, opacity_lo, opacity_hi, seed, w=15, h=15):
     """`n_layers` wide Gaussians over one 16x16 tile: every pixel's list is n_layers deep."""
     g = torch.Generator().manual_seed(seed)

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 mkdir -p gpurun_out/clustered_ab
 for v in intree "$@"; do
   if [ "$v" = intree ]; then unset GCP_LIBRARY; else export GCP_LIBRARY=$PWD/variants/$v.so; fi
-  python3 tools/clustered_bench.py 0 4 8 > gpurun_out/clustered_ab/$v.log 2>&1
+  python3 ${GCP_AB_TOOL:-tools/clustered_bench.py} ${GCP_AB_ARGS:-0 4 8} > gpurun_out/clustered_ab/$v.log 2>&1
   python3 - $v gpurun_out/clustered_ab/$v.log <<'PY'
 import json, sys
 for line in open(sys.argv[2]):

@@ -169,6 +169,41 @@ def row_bands(height: int, world_size: int, tile: int = 16) -> List[tuple]:
     return bands
 
 
+def row_bands_by_pairs(startpoint: torch.Tensor, endpoint: torch.Tensor, height: int, world_size: int, tile: int = 16) -> List[tuple]:
+    """`row_bands` with the cuts placed by WORK: contiguous bands of whole tile rows holding about the same number of
+    splat-pixel pairs each, instead of the same number of rows — a scene whose Gaussians crowd one part of the frame would
+    otherwise leave the ranks of the other parts idle (the same imbalance the tile-list walk had between XCDs, DESIGN.md
+    §3.4).  Pairs per pixel row come from the boxes alone (a difference array over the rows: O(N + H)); the cut in front of
+    rank r is the tile-row boundary nearest to r / world_size of the pairs.  Pure index arithmetic on the boxes: identical on
+    every rank.  Bands may be empty, as in `row_bands`."""
+    n_tile_rows = (height + 1 + tile - 1) // tile
+    s = startpoint.detach().to("cpu", torch.int64)
+    e = endpoint.detach().to("cpu", torch.int64)
+    y0, y1 = s[:, 1].clamp(min=0), e[:, 1].clamp(max=height)
+    wd = (e[:, 0] - s[:, 0] + 1).clamp(min=0)
+    ok = (y1 >= y0) & (wd > 0)
+    diff = torch.zeros(height + 2, dtype=torch.int64)
+    diff.index_add_(0, y0[ok], wd[ok])
+    diff.index_add_(0, y1[ok] + 1, -wd[ok])
+    per_row = torch.cumsum(diff, 0)[: height + 1]
+    pad = n_tile_rows * tile - (height + 1)
+    per_tile_row = torch.cat([per_row, torch.zeros(pad, dtype=torch.int64)]).reshape(n_tile_rows, tile).sum(1)
+    ends = torch.cumsum(per_tile_row, 0)  # pairs in tile rows [0, t]
+    total = int(ends[-1].item()) if n_tile_rows else 0
+    if total == 0:
+        return row_bands(height, world_size, tile)
+    cuts = [0]
+    for r in range(1, world_size):
+        target = (total * r) // world_size
+        t = int(torch.searchsorted(ends, torch.tensor(target, dtype=torch.int64), right=False).item())  # first t with ends[t] >= target
+        t = min(t, n_tile_rows - 1)
+        before = int(ends[t - 1].item()) if t > 0 else 0
+        cut = t + 1 if (int(ends[t].item()) - target) <= (target - before) else t
+        cuts.append(max(cuts[-1], min(cut, n_tile_rows)))
+    cuts.append(n_tile_rows)
+    return [(cuts[r] * tile, min(cuts[r + 1] * tile - 1, height)) for r in range(world_size)]
+
+
 def band_view(startpoint: torch.Tensor, endpoint: torch.Tensor, mean: torch.Tensor, band: tuple):
     """Inputs of the blend for one band: y coordinates shifted so the band starts at row 0 and boxes cut
     to the band (a box that misses the band becomes empty and is skipped by the kernels; depth order is

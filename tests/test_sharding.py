@@ -127,6 +127,43 @@ def test_row_bands_cover_the_frame_on_tile_boundaries():
         assert all(y0 % 16 == 0 for (y0, y1) in bands if y1 >= y0)
 
 
+def test_row_bands_by_pairs_balance_a_scene_that_crowds_one_region():
+    """Bands cut by work: the same coverage rules as `row_bands` (whole tile rows, contiguous, the whole frame), and on a scene
+    whose boxes crowd the middle of the frame the heaviest band holds little more than its share of the pairs where equal-row
+    bands leave most of them to the middle ranks."""
+    g = torch.Generator().manual_seed(5)
+    h, w, n, world = 1079, 1919, 20000, 8
+    cy = (torch.randn(n, generator=g) * (h / 8) + h / 2).round().clamp(0, h).long()
+    cx = torch.randint(0, w + 1, (n,), generator=g)
+    half = torch.randint(1, 9, (n, 2), generator=g)
+    start = torch.stack([(cx - half[:, 0]).clamp(min=0), (cy - half[:, 1]).clamp(min=0)], 1).to(torch.int32)
+    end = torch.stack([(cx + half[:, 0]).clamp(max=w), (cy + half[:, 1]).clamp(max=h)], 1).to(torch.int32)
+
+    def pairs_in(band):
+        y0, y1 = band
+        if y1 < y0:
+            return 0
+        rows = (torch.minimum(end[:, 1].long(), torch.tensor(y1)) - torch.maximum(start[:, 1].long(), torch.tensor(y0)) + 1).clamp(min=0)
+        return int((rows * (end[:, 0] - start[:, 0] + 1).long()).sum())
+
+    total = pairs_in((0, h))
+    for world in (8, 3, 2):
+        bands = sharding.row_bands_by_pairs(start, end, h, world)
+        rows = [y for (y0, y1) in bands for y in range(y0, y1 + 1)]
+        assert rows == list(range(h + 1)) and all(y0 % 16 == 0 for (y0, y1) in bands if y1 >= y0)
+        assert sum(pairs_in(b) for b in bands) == total
+        heaviest = max(pairs_in(b) for b in bands)
+        even = max(pairs_in(b) for b in sharding.row_bands(h, world))
+        one_tile_row = max(pairs_in((t * 16, min(t * 16 + 15, h))) for t in range((h + 16) // 16))
+        assert heaviest <= total / world + one_tile_row          # within one tile row of the ideal share
+        if world == 8:
+            assert even > 2.5 * total / world and heaviest < 1.5 * total / world
+    # degenerate inputs: no boxes at all -> the equal-row bands; more ranks than tile rows -> empty bands, still a cover
+    assert sharding.row_bands_by_pairs(start[:0], end[:0], 47, 3) == sharding.row_bands(47, 3)
+    bands = sharding.row_bands_by_pairs(start, end.clamp(max=29), 29, 5)
+    assert [y for (y0, y1) in bands for y in range(y0, y1 + 1)] == list(range(30))
+
+
 def _band_worker(rank, world, port, q, w=40, h=45):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

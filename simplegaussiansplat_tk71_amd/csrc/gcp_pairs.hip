@@ -445,9 +445,14 @@ __global__ __launch_bounds__(256) void k_cut_finish(const int* __restrict__ info
                                                     const unsigned long long* __restrict__ block_sum, i64 n_blocks, i64 rect_capacity,
                                                     int* __restrict__ info8) {
   __shared__ unsigned long long s_part[256];
-  unsigned long long part = 0;  // integer adds in a fixed order: the same total every time
-#pragma unroll 8
-  for (i64 j = threadIdx.x; j < n_blocks; j += 256) part += block_sum[j];
+  unsigned long long part = 0;  // integer adds: the same total whatever the order
+  for (i64 j0 = threadIdx.x; j0 < n_blocks; j0 += 8 * 256) {  // eight loads in flight per thread
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (j0 + u * 256 < n_blocks) ? block_sum[j0 + u * 256] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part += v[u];
+  }
   s_part[threadIdx.x] = part;
   __syncthreads();
   if (threadIdx.x != 0) return;

@@ -13,6 +13,14 @@ from tests.util import TOL, assert_parity, make_scene
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["cells", "filter"], autouse=True)
+def look_table(request, monkeypatch):
+    """Every test of this file twice: with the pairs looking at the cells themselves (what lists below 2^25 pairs do) and at
+    the 16-bit filter table (what larger lists do) — GCP_PIXELS_FILTER_FROM moves the switch (csrc/gcp_pixels.hip)."""
+    monkeypatch.setenv("GCP_PIXELS_FILTER_FROM", "0" if request.param == "filter" else str(1 << 40))
+    return request.param
+
+
 def _bits(t):
     return t.detach().cpu().numpy().view(np.int32)
 

@@ -177,7 +177,7 @@ def test_walk_compaction_and_blend_kernels_use_no_scratch(tmp_path):
 
 def test_chunk_carry_entry_points_validate_without_a_gpu_and_the_reference_names_exist():
     """Row f3 widened: the argument checks of gcp_pixels_min / gcp_pixels_range return before any HIP call; the workspace covers
-    the pixel table; the reference's helper names (gs_model.py:480-594, :716-730) are static methods of the Function class."""
+    the pixel table and its filter; the reference's helper names (gs_model.py:480-594, :716-730) are static methods of the Function class."""
     import pytest
     import torch
 
@@ -186,7 +186,7 @@ def test_chunk_carry_entry_points_validate_without_a_gpu_and_the_reference_names
 
     lib = _lib.load()
     b = lib.gcp_pixels_min_workspace_bytes(1919, 1079)
-    assert b % 256 == 0 and 1920 * 1080 * 4 <= b < 1920 * 1080 * 4 + (1 << 20)
+    assert b % 256 == 0 and 1920 * 1080 * 6 <= b < 1920 * 1080 * 6 + (1 << 20)   # 32-bit cells + the 16-bit filter table
     assert lib.gcp_pixels_min_workspace_bytes(-1, 5) == 0
     assert lib.gcp_pixels_min_workspace_bytes(1 << 20, 1 << 20) == 0            # beyond the table the call holds
     assert lib.gcp_pixels_min(None, 0, None, -1, 10, 10, None, None, 0, None, None, 0, None) == 1

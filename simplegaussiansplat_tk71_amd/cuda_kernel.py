@@ -492,7 +492,8 @@ def create_alpha_brend_min(rects, T, *, image_size=None):
     `scatter_reduce(0, inv, T, "amin", include_self=False)`.  Here: ONE pass over the list, every pair taking the minimum
     with its pixel's cell of an image-sized table, and the table read out in (x, y) order (csrc/gcp_pixels.hip); nothing
     M-sized is sorted or written.  Returns [unique_rects (dtype of rects, the rows torch.unique returns in its order),
-    T_min f32] bit for bit — a minimum does not depend on the order it is taken in.  Keyword-only extension:
+    T_min f32] bit for bit — a minimum does not depend on the order it is taken in (one exception that is none: -0 == +0, and a
+    pixel holding both returns -0 here, whichever its reduction met first in the reference).  Keyword-only extension:
     image_size=(width, height), what the Function holds (gs_model.py:666), spares the pass that finds the list's extent;
     a PreparedRects brings it along."""
     with torch.no_grad():

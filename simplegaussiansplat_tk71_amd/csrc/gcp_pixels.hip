@@ -23,7 +23,6 @@ using namespace gcp;
 
 constexpr unsigned kNoPair = 0xffffffffu;  // a cell no pair has touched
 constexpr int kPairTile = 4096;            // pairs per block: 16 steps of 256 threads
-constexpr int kCellTile = 1024;            // cells per block in the read-out: 4 consecutive ones per thread
 
 // fp32 -> unsigned with the same order (a < b  <=>  enc(a) < enc(b), -0 below +0).  NaN -> 0, the smallest image, which
 // decodes to a NaN: a pixel with a NaN among its values comes out NaN, as `amin` has it.  0xffffffff is no value's image
@@ -155,58 +154,64 @@ __global__ __launch_bounds__(256) void k_pixels_min(const void* __restrict__ rec
 }
 
 // ---- pass 2: the table read out in (x, y) order ------------------------------------------------------------------------------
-// cell j of the read-out order is pixel (x, y) = (j / h1, j % h1).  WRITE = false: touched cells per block; WRITE = true:
-// the rows of the result at the block's offset + the rank inside the block.
+// The result lists the touched cells column by column ((x, y) ascending: the row order of torch.unique(dim=0)), the table is
+// stored row by row.  A block takes a PATCH of 16 columns x 128 rows: it reads the patch with 64-byte row segments into LDS
+// (a thread that walked a column of the table itself fetched a 64-byte sector for every 4-byte cell), and each wave walks
+// four of the patch's columns there, its lanes over consecutive rows.  The (column, row band) pieces are contiguous runs of
+// the result in the order column-major, band-minor: one count per piece, ONE exclusive scan over all pieces, ranked writes —
+// neighbouring lanes write neighbouring rows of the result.
+constexpr int kColTile = 16, kBandRows = 128, kColStride = 17;  // (stride 17: a column walk touches 64 different banks)
 template <bool WRITE, bool I64, bool INDEX>
-__global__ __launch_bounds__(256) void k_pixels_readout(const unsigned* __restrict__ cell, int w1, int h1, int* __restrict__ cnt,
+__global__ __launch_bounds__(256) void k_pixels_readout(const unsigned* __restrict__ cell, int w1, int h1, int bands, int* __restrict__ cnt,
                                                         const int* __restrict__ off, i64 capacity, void* __restrict__ out_xy,
                                                         float* __restrict__ out_val, int* __restrict__ info) {
-  __shared__ int s_w[4];
+  __shared__ unsigned s_tile[kBandRows * kColStride];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const i64 cells = (i64)w1 * h1;
-  const i64 j0 = (i64)blockIdx.x * kCellTile + (i64)threadIdx.x * 4;
-  unsigned u[4];
-  int x[4], y[4];
+  const int x0 = blockIdx.x * kColTile, band = blockIdx.y, y0 = band * kBandRows;
+  unsigned u[kBandRows * kColTile / 256];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const i64 j = j0 + k < cells ? j0 + k : cells - 1;
-    x[k] = (int)(j / h1);
-    y[k] = (int)(j - (i64)x[k] * h1);
-    u[k] = cell[(size_t)y[k] * w1 + x[k]];
+  for (int j = 0; j < kBandRows * kColTile / 256; ++j) {  // eight loads per thread, all issued before the first LDS store
+    const int i = j * 256 + threadIdx.x, r = i >> 4, xx = i & 15;
+    const bool in = x0 + xx < w1 && y0 + r < h1;
+    u[j] = cell[in ? (size_t)(y0 + r) * w1 + x0 + xx : 0];
+    if (!in) u[j] = kNoPair;
   }
-  int c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) c += (j0 + k < cells && u[k] != kNoPair) ? 1 : 0;
-  const int inc = wave_incl_scan_i(c);
-  if (lane == 63) s_w[w] = inc;
+  for (int j = 0; j < kBandRows * kColTile / 256; ++j) {
+    const int i = j * 256 + threadIdx.x;
+    s_tile[(i >> 4) * kColStride + (i & 15)] = u[j];
+  }
   __syncthreads();
-  const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-  if (!WRITE) {
-    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
-    return;
-  }
-  int before = inc - c;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (q < w) before += s_w[q];
-  i64 o = (i64)off[blockIdx.x] + before;
+  for (int c = 0; c < kColTile / 4; ++c) {
+    const int xx = w + 4 * c;  // wave w: columns w, w + 4, w + 8, w + 12 of the patch
+    if (x0 + xx >= w1) break;  // wave-uniform
+    const int piece = (x0 + xx) * bands + band;
+    const unsigned v0 = s_tile[lane * kColStride + xx], v1 = s_tile[(lane + 64) * kColStride + xx];
+    const unsigned long long m0 = __ballot(v0 != kNoPair), m1 = __ballot(v1 != kNoPair);
+    if (!WRITE) {
+      if (lane == 0) cnt[piece] = __builtin_popcountll(m0) + __builtin_popcountll(m1);
+      continue;
+    }
+    const i64 o = off[piece];
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (j0 + k < cells && u[k] != kNoPair) {
-      if (o < capacity) {
+    for (int half = 0; half < 2; ++half) {
+      const unsigned v = half ? v1 : v0;
+      const i64 at = o + (half ? __builtin_popcountll(m0) : 0) + __builtin_popcountll((half ? m1 : m0) & below);
+      if (v != kNoPair && at < capacity) {
+        const int y = y0 + lane + 64 * half;
         if (I64) {
-          reinterpret_cast<long long*>(out_xy)[2 * o] = x[k];
-          reinterpret_cast<long long*>(out_xy)[2 * o + 1] = y[k];
+          reinterpret_cast<long long*>(out_xy)[2 * at] = x0 + xx;
+          reinterpret_cast<long long*>(out_xy)[2 * at + 1] = y;
         } else {
-          reinterpret_cast<int2*>(out_xy)[o] = make_int2(x[k], y[k]);
+          reinterpret_cast<int2*>(out_xy)[at] = make_int2(x0 + xx, y);
         }
-        // INDEX: the reference carries the index through fp32 (gs_model.py:728 `index.to(torch.float32)`): the float it is
-        out_val[o] = INDEX ? (float)u[k] : dec_f32(u[k]);
+        out_val[at] = INDEX ? (float)v : dec_f32(v);  // (INDEX: the float the reference carries the index in, gs_model.py:728)
       }
-      ++o;
     }
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) info[0] = off[blockIdx.x] + total;
+  if (WRITE && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) info[0] = off[(i64)w1 * bands];  // the scan's total
 }
 
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
@@ -218,7 +223,7 @@ struct PixelsWs {
 inline PixelsWs pixels_ws(i64 w1, i64 h1) {
   PixelsWs w;
   const i64 cells = w1 * h1;
-  w.blocks = (cells + kCellTile - 1) / kCellTile;
+  w.blocks = w1 * ((h1 + kBandRows - 1) / kBandRows);  // (column, row band) pieces of the read-out
   size_t o = 0;
   w.cell = o; o += align256((size_t)cells * sizeof(unsigned));
   w.filter = o; o += align256((size_t)cells * sizeof(unsigned short));
@@ -288,14 +293,15 @@ int gcp_pixels_min(const void* rects_xy, int32_t rects_are_int64, const float* v
   else { if (index) GCP_PIXELS_MIN(false, true); else GCP_PIXELS_MIN(false, false); }
 #undef GCP_PIXELS_MIN
   GCP_HIP(hipGetLastError());
-  const unsigned cell_blocks = (unsigned)L.blocks;
-  hipLaunchKernelGGL((k_pixels_readout<false, false, false>), dim3(cell_blocks), dim3(256), 0, stream, (const unsigned*)cell, (int)w1, (int)h1, cnt,
+  const int bands = (int)((h1 + kBandRows - 1) / kBandRows);
+  const dim3 rgrid((unsigned)((w1 + kColTile - 1) / kColTile), (unsigned)bands);
+  hipLaunchKernelGGL((k_pixels_readout<false, false, false>), rgrid, dim3(256), 0, stream, (const unsigned*)cell, (int)w1, (int)h1, bands, cnt,
                      (const int*)nullptr, (i64)0, (void*)nullptr, (float*)nullptr, (int*)nullptr);
   GCP_HIP(hipGetLastError());
   const int st = gcp_exclusive_scan_i32(cnt, off, L.blocks, base + L.scan, gcp_scan_i32_workspace_bytes(L.blocks), stream_);
   if (st != GCP_OK) return st;
-#define GCP_PIXELS_OUT(I64, INDEX)                                                                                                         \
-  hipLaunchKernelGGL((k_pixels_readout<true, I64, INDEX>), dim3(cell_blocks), dim3(256), 0, stream, (const unsigned*)cell, (int)w1, (int)h1, \
+#define GCP_PIXELS_OUT(I64, INDEX)                                                                                                     \
+  hipLaunchKernelGGL((k_pixels_readout<true, I64, INDEX>), rgrid, dim3(256), 0, stream, (const unsigned*)cell, (int)w1, (int)h1, bands, \
                      (int*)nullptr, (const int*)off, (i64)capacity, out_xy, out_val, info)
   if (wide) { if (index) GCP_PIXELS_OUT(true, true); else GCP_PIXELS_OUT(true, false); }
   else { if (index) GCP_PIXELS_OUT(false, true); else GCP_PIXELS_OUT(false, false); }

@@ -169,6 +169,26 @@ def test_random_lists_against_the_oracle(device, seed):
     assert torch.equal(u.cpu(), wu) and np.array_equal(_bits(gm), _bits(wg)), seed
 
 
+@pytest.mark.parametrize("w,h", [(30, 2160), (70, 127), (5, 128), (40, 255), (1, 9000), (4000, 3), (15, 15), (16, 16), (17, 1), (0, 0), (0, 300), (300, 0)])
+def test_read_out_on_images_of_every_shape(device, w, h):
+    """The table is read out in patches of 16 columns x 128 rows through LDS, the (column, row band) pieces ranked by one scan:
+    narrow, tall, wide and one-row images, widths around the 16-column patch, heights around the 128-row band."""
+    from oracle import wrappers as ow
+    from simplegaussiansplat_tk71_amd import cuda_kernel as ck
+
+    g = torch.Generator().manual_seed(w * 10007 + h)
+    n = 50_000
+    r = torch.stack((torch.randint(0, w + 1, (n,), generator=g), torch.randint(0, h + 1, (n,), generator=g)), 1).to(torch.int32)
+    r[:7] = torch.tensor([[0, 0], [w, h], [w, 0], [0, h], [w // 2, h // 2], [min(15, w), h], [min(16, w), 0]], dtype=torch.int32)
+    v = torch.rand(n, generator=g)
+    wu, wm = ow.create_alpha_brend_min(r, v)
+    u, m = ck.create_alpha_brend_min(r.to(device), v.to(device), image_size=(w, h))
+    assert torch.equal(u.cpu(), wu) and np.array_equal(_bits(m), _bits(wm))
+    wu, wg = ow.create_grad_alphabrend_min(r.long(), v)
+    u, gm = ck.create_grad_alphabrend_min(r.long().to(device), v.to(device))
+    assert u.dtype == torch.int64 and torch.equal(u.cpu(), wu) and np.array_equal(_bits(gm), _bits(wg))
+
+
 def test_edges_empty_one_pixel_nan_and_coordinates_outside(device):
     from simplegaussiansplat_tk71_amd import cuda_kernel as ck
 

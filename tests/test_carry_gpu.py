@@ -17,6 +17,12 @@ pytestmark = pytest.mark.gpu
 def look_table(request, monkeypatch):
     """Every test of this file twice: with the pairs looking at the cells themselves (what lists below 2^25 pairs do) and at
     the 16-bit filter table (what larger lists do) — GCP_PIXELS_FILTER_FROM moves the switch (csrc/gcp_pixels.hip)."""
+    # the three long tests run once, under the table their list sizes take anyway (or, the scene-size oracle test, the other one)
+    once = {"test_cfg3_scene_properties": "filter", "test_first_pair_index_travels_as_a_float_like_the_reference": "cells",
+            "test_against_the_oracle_at_scene_size_and_on_lists_of_unrelated_coordinates": "filter"}
+    name = request.node.originalname or request.node.name
+    if name in once and once[name] != request.param:
+        pytest.skip("long test: run under the other look table only")
     monkeypatch.setenv("GCP_PIXELS_FILTER_FROM", "0" if request.param == "filter" else str(1 << 40))
     return request.param
 
